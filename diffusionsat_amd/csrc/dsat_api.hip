@@ -1,0 +1,923 @@
+// C-ABI layer (include/dsat.h): graph / weights / session objects and the launch
+// sequence of one denoising step.  Host-side orchestration only; the kernels are in
+// kernels_*.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "dsat_internal.h"
+
+namespace dsat {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file,
+             line, what);
+    g_last_error = buf;
+    return DSAT_E_HIP;
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+template <typename T>
+static hipError_t up(T** dst, const T* src, size_t n) {
+    hipError_t e = hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (n) e = hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+// ---- bump allocator over one hipMalloc slab -------------------------------------
+struct Slab {
+    char* base = nullptr;
+    size_t size = 0, off = 0;
+    bool dry = true;
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+// ---- layout ----------------------------------------------------------------------
+// Input blocks of the first layer of each MLP (concat members of query_sat.py:239,
+// :258, :277) as (logical k, padded k).
+static std::vector<BlockSpec> first_layer_blocks(int mlp) {
+    switch (mlp) {
+        case DSAT_MLP_VARIABLES_QUERY:
+        case DSAT_MLP_LIT:
+            return {{F, F}, {AUX_USED, AUX_W}};
+        case DSAT_MLP_CLAUSE:
+            return {{F, F}, {F, F}, {F, F}};
+        case DSAT_MLP_UPDATE_GATE:
+            return {{F, F}, {F, F}, {AUX_USED, AUX_W}, {F, F}, {F, F}};
+        default:
+            return {{F, F}};
+    }
+}
+
+static int layer_dims(const dsat_layout* L, int mlp, int layer, int* in_dim, int* out_dim) {
+    if (mlp < 0 || mlp >= DSAT_N_MLP || layer < 0 || layer >= L->n_layers[mlp]) return DSAT_E_INVALID;
+    const int v1 = L->feature_maps + AUX_USED;
+    const int in0[DSAT_N_MLP] = {v1, v1, L->feature_maps + 2 * L->query_maps,
+                                 L->query_maps + v1 + 2 * L->query_maps, L->feature_maps};
+    const int outl[DSAT_N_MLP] = {L->query_maps, 2 * L->query_maps, L->feature_maps + L->query_maps,
+                                  L->feature_maps, L->logit_maps};
+    const int last = L->n_layers[mlp] - 1;
+    *in_dim = layer == 0 ? in0[mlp] : L->hidden[mlp];
+    *out_dim = layer == last ? outl[mlp] : L->hidden[mlp];
+    return DSAT_OK;
+}
+
+}  // namespace dsat
+
+using namespace dsat;
+
+// ============================================================================ misc
+extern "C" const char* dsat_last_error(void) { return g_last_error.c_str(); }
+extern "C" int32_t dsat_version(void) { return 100; }
+
+extern "C" int dsat_default_layout(dsat_layout* out) {
+    DSAT_REQUIRE(out != nullptr, DSAT_E_INVALID, "dsat_default_layout: null out");
+    out->feature_maps = 128;
+    out->query_maps = 128;
+    out->logit_maps = 8;
+    const int nl[DSAT_N_MLP] = {2, 3, 2, 3, 2};
+    // int(128*1.2), 128*4, int(128*1.6), int(128*1.8), int(128*1)   (query_sat.py:109-122)
+    const int hd[DSAT_N_MLP] = {153, 512, 204, 230, 128};
+    for (int i = 0; i < DSAT_N_MLP; ++i) { out->n_layers[i] = nl[i]; out->hidden[i] = hd[i]; }
+    return DSAT_OK;
+}
+
+extern "C" int dsat_layout_layer_dims(const dsat_layout* layout, int32_t mlp, int32_t layer,
+                                       int32_t* in_dim, int32_t* out_dim) {
+    DSAT_REQUIRE(layout && in_dim && out_dim, DSAT_E_INVALID, "dsat_layout_layer_dims: null argument");
+    int i, o;
+    if (layer_dims(layout, mlp, layer, &i, &o) != DSAT_OK) {
+        set_error("dsat_layout_layer_dims: mlp/layer out of range");
+        return DSAT_E_INVALID;
+    }
+    *in_dim = i;
+    *out_dim = o;
+    return DSAT_OK;
+}
+
+extern "C" int64_t dsat_layout_blob_floats(const dsat_layout* layout) {
+    if (!layout) return -1;
+    int64_t n = 0;
+    for (int m = 0; m < DSAT_N_MLP; ++m)
+        for (int l = 0; l < layout->n_layers[m]; ++l) {
+            int i, o;
+            if (layer_dims(layout, m, l, &i, &o) != DSAT_OK) return -1;
+            n += (int64_t)i * o + o;
+        }
+    return n;
+}
+
+static int check_layout(const dsat_layout* L) {
+    DSAT_REQUIRE(L != nullptr, DSAT_E_INVALID, "null layout");
+    DSAT_REQUIRE(L->feature_maps == F && L->query_maps == F, DSAT_E_UNSUPPORTED,
+                 "kernels are built for feature_maps = query_maps = 128 only");
+    DSAT_REQUIRE(L->logit_maps == LOGIT_MAPS, DSAT_E_UNSUPPORTED, "kernels are built for logit_maps = 8 only");
+    for (int m = 0; m < DSAT_N_MLP; ++m) {
+        DSAT_REQUIRE(L->n_layers[m] >= 2 && L->n_layers[m] <= 4, DSAT_E_UNSUPPORTED,
+                     "each MLP needs 2..4 layers (query_sat.py:101-104)");
+        DSAT_REQUIRE(L->hidden[m] >= 1 && L->hidden[m] <= 1024, DSAT_E_UNSUPPORTED,
+                     "hidden width out of range (1..1024)");
+    }
+    return DSAT_OK;
+}
+
+// ============================================================================ graph
+extern "C" int dsat_graph_create(const int32_t* clause_rowptr, const int32_t* clause_lits,
+                                  const int32_t* var_graph_id, const int32_t* clause_graph_id,
+                                  int32_t N, int32_t C, int32_t G, dsat_graph** out) {
+    DSAT_REQUIRE(out != nullptr, DSAT_E_INVALID, "dsat_graph_create: null out");
+    *out = nullptr;
+    DSAT_REQUIRE(N > 0 && C >= 0 && G > 0, DSAT_E_INVALID, "dsat_graph_create: need n_vars>0, n_clauses>=0, n_graphs>0");
+    DSAT_REQUIRE(clause_rowptr && var_graph_id && (C == 0 || clause_graph_id), DSAT_E_INVALID,
+                 "dsat_graph_create: null input array");
+    DSAT_REQUIRE(clause_rowptr[0] == 0, DSAT_E_INVALID, "dsat_graph_create: clause_rowptr[0] must be 0");
+    for (int c = 0; c < C; ++c)
+        DSAT_REQUIRE(clause_rowptr[c + 1] >= clause_rowptr[c], DSAT_E_INVALID,
+                     "dsat_graph_create: clause_rowptr must be non-decreasing");
+    const int64_t E = clause_rowptr[C];
+    DSAT_REQUIRE(E == 0 || clause_lits != nullptr, DSAT_E_INVALID, "dsat_graph_create: null clause_lits");
+    DSAT_REQUIRE((int64_t)2 * N < (int64_t)1 << 30 && E < ((int64_t)1 << 31) - 1, DSAT_E_INVALID,
+                 "dsat_graph_create: graph too large for int32 indexing");
+
+    std::vector<int32_t> vseg(G + 1, 0), cseg(G + 1, 0);
+    for (int v = 0; v < N; ++v) {
+        const int g = var_graph_id[v];
+        DSAT_REQUIRE(g >= 0 && g < G, DSAT_E_INVALID, "dsat_graph_create: var_graph_id out of range");
+        DSAT_REQUIRE(v == 0 || g >= var_graph_id[v - 1], DSAT_E_INVALID,
+                     "dsat_graph_create: var_graph_id must be non-decreasing (graphs are contiguous)");
+        vseg[g + 1]++;
+    }
+    for (int c = 0; c < C; ++c) {
+        const int g = clause_graph_id[c];
+        DSAT_REQUIRE(g >= 0 && g < G, DSAT_E_INVALID, "dsat_graph_create: clause_graph_id out of range");
+        DSAT_REQUIRE(c == 0 || g >= clause_graph_id[c - 1], DSAT_E_INVALID,
+                     "dsat_graph_create: clause_graph_id must be non-decreasing (graphs are contiguous)");
+        cseg[g + 1]++;
+    }
+    for (int g = 0; g < G; ++g) {
+        DSAT_REQUIRE(vseg[g + 1] > 0, DSAT_E_INVALID, "dsat_graph_create: a graph has no variables");
+        vseg[g + 1] += vseg[g];
+        cseg[g + 1] += cseg[g];
+    }
+
+    // clause -> literal rows, literal degrees
+    std::vector<int32_t> c_lit(E), l_rowptr(2 * (size_t)N + 1, 0);
+    int32_t max_len = 0;
+    for (int c = 0; c < C; ++c) {
+        const int g = clause_graph_id[c];
+        max_len = std::max(max_len, clause_rowptr[c + 1] - clause_rowptr[c]);
+        for (int e = clause_rowptr[c]; e < clause_rowptr[c + 1]; ++e) {
+            const int32_t l = clause_lits[e];
+            const int32_t v = (l > 0 ? l : -l) - 1;
+            DSAT_REQUIRE(l != 0 && v < N, DSAT_E_INVALID, "dsat_graph_create: literal out of range");
+            DSAT_REQUIRE(var_graph_id[v] == g, DSAT_E_INVALID,
+                         "dsat_graph_create: a clause references a variable of another graph");
+            const int32_t row = l > 0 ? v : v + N;   // SatSpecifics.py:25-35
+            c_lit[e] = row;
+            l_rowptr[row + 1]++;
+        }
+    }
+    int32_t max_deg = 0;
+    for (size_t i = 0; i < 2 * (size_t)N; ++i) {
+        max_deg = std::max(max_deg, l_rowptr[i + 1]);
+        l_rowptr[i + 1] += l_rowptr[i];
+    }
+    // literal -> clause rows (counting sort: clauses ascending within a literal)
+    std::vector<int32_t> l_clause(E), cursor(l_rowptr.begin(), l_rowptr.end() - 1);
+    for (int c = 0; c < C; ++c)
+        for (int e = clause_rowptr[c]; e < clause_rowptr[c + 1]; ++e) l_clause[cursor[c_lit[e]]++] = c;
+
+    // degree weights, query_sat.py:193-197
+    std::vector<float> deg_w(2 * (size_t)N), vdeg_w(N), rev_w(std::max(C, 1));
+    for (size_t i = 0; i < 2 * (size_t)N; ++i) {
+        const float d = (float)(l_rowptr[i + 1] - l_rowptr[i]);
+        deg_w[i] = 1.0f / std::sqrt(std::max(d, 1.0f));
+    }
+    for (int v = 0; v < N; ++v) {
+        const float d = (float)(l_rowptr[v + 1] - l_rowptr[v]) + (float)(l_rowptr[N + v + 1] - l_rowptr[N + v]);
+        vdeg_w[v] = 4.0f * (1.0f / std::sqrt(std::max(d, 1.0f)));
+    }
+    for (int c = 0; c < C; ++c) {
+        const float d = (float)(clause_rowptr[c + 1] - clause_rowptr[c]);
+        rev_w[c] = 1.0f / std::sqrt(std::max(d, 1.0f));
+    }
+
+    std::unique_ptr<dsat_graph> g(new dsat_graph());
+    g->N = N; g->C = C; g->G = G; g->E = E;
+    g->max_clause_len = max_len; g->max_lit_deg = max_deg;
+    g->h_var_seg = vseg; g->h_cl_seg = cseg;
+    hipError_t e = hipSuccess;
+    if ((e = up(&g->c_rowptr, clause_rowptr, (size_t)C + 1)) != hipSuccess ||
+        (e = up(&g->c_lit, c_lit.data(), (size_t)E)) != hipSuccess ||
+        (e = up(&g->l_rowptr, l_rowptr.data(), 2 * (size_t)N + 1)) != hipSuccess ||
+        (e = up(&g->l_clause, l_clause.data(), (size_t)E)) != hipSuccess ||
+        (e = up(&g->var_gid, var_graph_id, (size_t)N)) != hipSuccess ||
+        (e = up(&g->cl_gid, clause_graph_id, (size_t)C)) != hipSuccess ||
+        (e = up(&g->var_seg, vseg.data(), (size_t)G + 1)) != hipSuccess ||
+        (e = up(&g->cl_seg, cseg.data(), (size_t)G + 1)) != hipSuccess ||
+        (e = up(&g->deg_w, deg_w.data(), 2 * (size_t)N)) != hipSuccess ||
+        (e = up(&g->vdeg_w, vdeg_w.data(), (size_t)N)) != hipSuccess ||
+        (e = up(&g->rev_w, rev_w.data(), (size_t)C)) != hipSuccess) {
+        dsat_graph_destroy(g.release());
+        return hip_fail(e, "graph upload", __FILE__, __LINE__);
+    }
+    *out = g.release();
+    return DSAT_OK;
+}
+
+extern "C" void dsat_graph_destroy(dsat_graph* g) {
+    if (!g) return;
+    void* ptrs[] = {g->c_rowptr, g->c_lit, g->l_rowptr, g->l_clause, g->var_gid, g->cl_gid,
+                    g->var_seg, g->cl_seg, g->deg_w, g->vdeg_w, g->rev_w};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+}
+
+extern "C" int dsat_graph_info(const dsat_graph* g, int32_t* n_vars, int32_t* n_clauses, int64_t* n_edges,
+                                int32_t* n_graphs) {
+    DSAT_REQUIRE(g != nullptr, DSAT_E_INVALID, "dsat_graph_info: null graph");
+    if (n_vars) *n_vars = g->N;
+    if (n_clauses) *n_clauses = g->C;
+    if (n_edges) *n_edges = g->E;
+    if (n_graphs) *n_graphs = g->G;
+    return DSAT_OK;
+}
+
+// ============================================================================ weights
+// Pack one Dense layer: wt[npad][kpad] = kernel^T with each input block padded to a
+// multiple of 16 along K and N padded to a multiple of 32, zeros elsewhere.
+static void pack_layer(const float* kernel, const float* bias, int in_dim, int out_dim,
+                       const std::vector<BlockSpec>& blocks, int npad, int n_off, int kpad, float* wt,
+                       float* bpad) {
+    int src = 0, dst = 0;
+    for (const BlockSpec& b : blocks) {
+        for (int j = 0; j < b.k; ++j)
+            for (int n = 0; n < out_dim; ++n) wt[(size_t)(n_off + n) * kpad + dst + j] = kernel[(size_t)(src + j) * out_dim + n];
+        src += b.k;
+        dst += b.kp;
+    }
+    (void)in_dim; (void)npad;
+    for (int n = 0; n < out_dim; ++n) bpad[n_off + n] = bias[n];
+}
+
+extern "C" int dsat_weights_load(const float* blob, int64_t n_floats, const dsat_layout* layout,
+                                  dsat_weights** out) {
+    DSAT_REQUIRE(out != nullptr, DSAT_E_INVALID, "dsat_weights_load: null out");
+    *out = nullptr;
+    int rc = check_layout(layout);
+    if (rc != DSAT_OK) return rc;
+    DSAT_REQUIRE(blob != nullptr, DSAT_E_INVALID, "dsat_weights_load: null blob");
+    const int64_t need = dsat_layout_blob_floats(layout);
+    DSAT_REQUIRE(n_floats == need, DSAT_E_INVALID,
+                 "dsat_weights_load: blob has " + std::to_string(n_floats) + " floats, layout needs " +
+                     std::to_string(need));
+    std::vector<float> host((size_t)need);
+    DSAT_HIP(hipMemcpy(host.data(), blob, (size_t)need * sizeof(float), hipMemcpyDefault));
+    for (int64_t i = 0; i < need; ++i)
+        DSAT_REQUIRE(std::isfinite(host[i]), DSAT_E_INVALID, "dsat_weights_load: blob holds a non-finite value");
+
+    std::unique_ptr<dsat_weights> w(new dsat_weights());
+    w->layout = *layout;
+    w->mlp.resize(DSAT_N_MLP);
+
+    struct Staged { PackedLayer* dst; std::vector<float> wt, bias; };
+    std::vector<Staged> staged;
+    const float* p = host.data();
+    const float* l0_kernel[2] = {nullptr, nullptr};
+    const float* l0_bias[2] = {nullptr, nullptr};
+    for (int m = 0; m < DSAT_N_MLP; ++m) {
+        w->mlp[m].resize(layout->n_layers[m]);
+        for (int l = 0; l < layout->n_layers[m]; ++l) {
+            int in_dim, out_dim;
+            layer_dims(layout, m, l, &in_dim, &out_dim);
+            const float* kernel = p;
+            const float* bias = p + (size_t)in_dim * out_dim;
+            p = bias + out_dim;
+            std::vector<BlockSpec> blocks = l == 0 ? first_layer_blocks(m)
+                                                    : std::vector<BlockSpec>{{in_dim, round_up(in_dim, 16)}};
+            PackedLayer& pl = w->mlp[m][l];
+            pl.in_dim = in_dim;
+            pl.out_dim = out_dim;
+            pl.kpad = 0;
+            for (auto& b : blocks) pl.kpad += b.kp;
+            pl.npad = round_up(out_dim, 32);
+            Staged s;
+            s.dst = &pl;
+            s.wt.assign((size_t)pl.npad * pl.kpad, 0.f);
+            s.bias.assign(pl.npad, 0.f);
+            pack_layer(kernel, bias, in_dim, out_dim, blocks, pl.npad, 0, pl.kpad, s.wt.data(), s.bias.data());
+            staged.push_back(std::move(s));
+            if (l == 0 && m <= DSAT_MLP_LIT) { l0_kernel[m] = kernel; l0_bias[m] = bias; }
+        }
+    }
+    // fused first layer of variables_query and lit_mlp: both consume v1 (query_sat.py:240, :252)
+    {
+        const int qh = layout->hidden[DSAT_MLP_VARIABLES_QUERY], lh = layout->hidden[DSAT_MLP_LIT];
+        w->q_hpad = round_up(qh, 32);
+        w->lit_h = lh;
+        PackedLayer& pl = w->ql1;
+        auto blocks = first_layer_blocks(DSAT_MLP_VARIABLES_QUERY);
+        pl.in_dim = F + AUX_USED;
+        pl.out_dim = w->q_hpad + lh;
+        pl.kpad = F + AUX_W;
+        pl.npad = w->q_hpad + round_up(lh, 32);
+        Staged s;
+        s.dst = &pl;
+        s.wt.assign((size_t)pl.npad * pl.kpad, 0.f);
+        s.bias.assign(pl.npad, 0.f);
+        pack_layer(l0_kernel[0], l0_bias[0], pl.in_dim, qh, blocks, pl.npad, 0, pl.kpad, s.wt.data(), s.bias.data());
+        pack_layer(l0_kernel[1], l0_bias[1], pl.in_dim, lh, blocks, pl.npad, w->q_hpad, pl.kpad, s.wt.data(), s.bias.data());
+        staged.push_back(std::move(s));
+    }
+    size_t total = 0;
+    for (auto& s : staged) total += ((s.wt.size() + 63) & ~size_t(63)) + ((s.bias.size() + 63) & ~size_t(63));
+    w->slab_bytes = total * sizeof(float);
+    DSAT_HIP(hipMalloc((void**)&w->slab, w->slab_bytes));
+    size_t off = 0;
+    for (auto& s : staged) {
+        s.dst->wt = w->slab + off;
+        hipError_t e = hipMemcpy(s.dst->wt, s.wt.data(), s.wt.size() * sizeof(float), hipMemcpyHostToDevice);
+        off += (s.wt.size() + 63) & ~size_t(63);
+        s.dst->bias = w->slab + off;
+        if (e == hipSuccess)
+            e = hipMemcpy(s.dst->bias, s.bias.data(), s.bias.size() * sizeof(float), hipMemcpyHostToDevice);
+        off += (s.bias.size() + 63) & ~size_t(63);
+        if (e != hipSuccess) {
+            dsat_weights_destroy(w.release());
+            return hip_fail(e, "weights upload", __FILE__, __LINE__);
+        }
+    }
+    *out = w.release();
+    return DSAT_OK;
+}
+
+extern "C" void dsat_weights_destroy(dsat_weights* w) {
+    if (!w) return;
+    if (w->slab) (void)hipFree(w->slab);
+    delete w;
+}
+
+// ============================================================================ session
+enum KernelClass { KC_GEMM_QL1 = 0, KC_GEMM_Q, KC_GEMM_LIT, KC_GEMM_CLAUSE, KC_GEMM_UPDATE, KC_GEMM_OUT,
+                   KC_CLAUSE_GATHER, KC_LITERAL_GATHER, KC_COLSUM, KC_PAIRNORM, KC_SELECT, KC_SATCHECK,
+                   KC_MISC, KC_COUNT };
+static const char* kKernelClassNames[KC_COUNT] = {
+    "gemm_query_lit_l1", "gemm_query", "gemm_lit", "gemm_clause", "gemm_update", "gemm_output",
+    "clause_gather", "literal_gather", "pairnorm_colsum", "pairnorm_apply", "select", "sat_check", "misc"};
+
+struct dsat_session {
+    const dsat_graph* g = nullptr;
+    const dsat_weights* w = nullptr;
+    int max_rounds = 0;
+    char* slab = nullptr;
+    size_t slab_bytes = 0;
+    // state + intermediates (see DESIGN.md "HBM layout")
+    float *V, *Vlog, *Cs, *q, *hq, *lits, *grad, *vl, *newv, *ho, *logits, *aux;
+    float *cmsg, *closs4, *vla, *ncv;
+    float* hid[DSAT_N_MLP][2];   // ping-pong hidden activations per MLP
+    int hid_ld[DSAT_N_MLP];
+    float *pv, *pc, *pgl, *out_logits;
+    int32_t *best, *graph_unsat, *labels, *in_labels, *fixed_step;
+    uint8_t *assign, *cum_acc;
+    float *in_noisy, *in_normal, *x0, *x1, *x_fixed, *scratch;
+    Ctl* ctl;
+    int nch_v = 1, nch_c = 1;
+    // graph replay
+    int use_graph = 1;
+    hipStream_t cap_stream = nullptr;
+    std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
+    // profiling
+    int profile = 0;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, int>> ev_used;  // (class, pool index of start)
+    double prof_us[KC_COUNT];
+    int64_t prof_n[KC_COUNT];
+};
+
+static void carve(dsat_session* s, Slab& sl) {
+    const dsat_graph* g = s->g;
+    const dsat_layout& L = s->w->layout;
+    const size_t N = g->N, C = std::max(g->C, 1), G = g->G, R = s->max_rounds;
+    s->V = sl.take<float>(N * F); s->Vlog = sl.take<float>(N * F); s->Cs = sl.take<float>(C * F);
+    s->q = sl.take<float>(N * F); s->hq = nullptr;
+    s->lits = sl.take<float>(2 * N * F); s->grad = sl.take<float>(N * F); s->vl = sl.take<float>(2 * N * F);
+    s->newv = sl.take<float>(N * F); s->ho = nullptr;
+    s->logits = sl.take<float>(N * LOGIT_MAPS); s->aux = sl.take<float>(R * N * AUX_W);
+    s->cmsg = sl.take<float>(C * F); s->closs4 = sl.take<float>(C * F);
+    s->vla = sl.take<float>(C * F); s->ncv = sl.take<float>(C * F);
+    for (int m = 0; m < DSAT_N_MLP; ++m) {
+        const size_t rows = (m == DSAT_MLP_CLAUSE) ? C : N;
+        s->hid_ld[m] = round_up(L.hidden[m], 32);
+        s->hid[m][0] = sl.take<float>(rows * s->hid_ld[m]);
+        s->hid[m][1] = sl.take<float>(rows * s->hid_ld[m]);
+    }
+    s->nch_v = colsum_chunks(g->G);
+    s->nch_c = colsum_chunks(g->G);
+    s->pv = sl.take<float>(G * s->nch_v * F); s->pc = sl.take<float>(G * s->nch_c * F);
+    s->pgl = sl.take<float>(G * LOGIT_MAPS); s->out_logits = sl.take<float>(N);
+    s->best = sl.take<int32_t>(G); s->graph_unsat = sl.take<int32_t>(G);
+    s->labels = sl.take<int32_t>(N); s->in_labels = sl.take<int32_t>(N); s->fixed_step = sl.take<int32_t>(G);
+    s->assign = sl.take<uint8_t>(N); s->cum_acc = sl.take<uint8_t>(G);
+    s->in_noisy = sl.take<float>(N * 2); s->in_normal = sl.take<float>(R * N * 4);
+    s->x0 = sl.take<float>(N); s->x1 = sl.take<float>(N); s->x_fixed = sl.take<float>(N);
+    // scratch for the single-operator entry points: packed MLP input, widest case
+    size_t max_k = 0;
+    for (int m = 0; m < DSAT_N_MLP; ++m) max_k = std::max<size_t>(max_k, s->w->mlp[m][0].kpad);
+    s->scratch = sl.take<float>(std::max(N, C) * max_k);
+    s->ctl = sl.take<Ctl>(1);
+}
+
+extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, int32_t max_rounds,
+                                    dsat_session** out) {
+    DSAT_REQUIRE(out != nullptr, DSAT_E_INVALID, "dsat_session_create: null out");
+    *out = nullptr;
+    DSAT_REQUIRE(g && w, DSAT_E_INVALID, "dsat_session_create: null graph or weights");
+    DSAT_REQUIRE(max_rounds >= 1 && max_rounds <= 4096, DSAT_E_INVALID, "dsat_session_create: max_rounds out of range");
+    std::unique_ptr<dsat_session> s(new dsat_session());
+    s->g = g; s->w = w; s->max_rounds = max_rounds;
+    Slab dry;
+    carve(s.get(), dry);
+    s->slab_bytes = dry.off + 256;
+    DSAT_HIP(hipMalloc((void**)&s->slab, s->slab_bytes));
+    hipError_t e = hipMemset(s->slab, 0, s->slab_bytes);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        (void)hipFree(s->slab);
+        return hip_fail(e, "session init", __FILE__, __LINE__);
+    }
+    Slab real;
+    real.base = s->slab; real.size = s->slab_bytes; real.dry = false;
+    carve(s.get(), real);
+    for (int i = 0; i < KC_COUNT; ++i) { s->prof_us[i] = 0; s->prof_n[i] = 0; }
+    *out = s.release();
+    return DSAT_OK;
+}
+
+extern "C" void dsat_session_destroy(dsat_session* s) {
+    if (!s) return;
+    for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+    if (s->cap_stream) (void)hipStreamDestroy(s->cap_stream);
+    if (s->slab) (void)hipFree(s->slab);
+    delete s;
+}
+
+extern "C" int dsat_session_set_graph_replay(dsat_session* s, int32_t enable) {
+    DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_graph_replay: null session");
+    s->use_graph = enable ? 1 : 0;
+    return DSAT_OK;
+}
+
+extern "C" int dsat_session_set_profile(dsat_session* s, int32_t enable) {
+    DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_profile: null session");
+    s->profile = enable ? 1 : 0;
+    return DSAT_OK;
+}
+
+// ---- profiled launch helper ------------------------------------------------------
+struct Launcher {
+    dsat_session* s;
+    hipStream_t st;
+    bool prof;
+    template <typename Fn>
+    void run(int cls, Fn&& fn) {
+        if (!prof) { fn(); return; }
+        const size_t i = s->ev_used.size() * 2;
+        while (s->ev_pool.size() < i + 2) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            s->ev_pool.push_back(e);
+        }
+        (void)hipEventRecord(s->ev_pool[i], st);
+        fn();
+        (void)hipEventRecord(s->ev_pool[i + 1], st);
+        s->ev_used.push_back({cls, (int)i});
+    }
+};
+
+static int collect_profile(dsat_session* s, hipStream_t st) {
+    DSAT_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < KC_COUNT; ++i) { s->prof_us[i] = 0; s->prof_n[i] = 0; }
+    for (auto& u : s->ev_used) {
+        float ms = 0.f;
+        DSAT_HIP(hipEventElapsedTime(&ms, s->ev_pool[u.second], s->ev_pool[u.second + 1]));
+        s->prof_us[u.first] += (double)ms * 1e3;
+        s->prof_n[u.first] += 1;
+    }
+    s->ev_used.clear();
+    return DSAT_OK;
+}
+
+extern "C" int dsat_session_profile(dsat_session* s, int32_t cap, const char** names, double* us_out,
+                                     int64_t* launches_out) {
+    DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_profile: null session");
+    for (int i = 0; i < KC_COUNT && i < cap; ++i) {
+        if (names) names[i] = kKernelClassNames[i];
+        if (us_out) us_out[i] = s->prof_n[i] ? s->prof_us[i] / (double)s->prof_n[i] : 0.0;
+        if (launches_out) launches_out[i] = s->prof_n[i];
+    }
+    return KC_COUNT;
+}
+
+// ---- MLP chains ---------------------------------------------------------------------
+struct OutSpec {
+    float* out0; float* out1; int ldo0, ldo1, split, nstore0, nstore1;
+};
+static OutSpec single_out(float* p, int ld, int nstore) { return {p, p, ld, ld, 1 << 30, nstore, 0}; }
+
+static GemmArgs make_gemm(const PackedLayer& pl, int M, int act, const OutSpec& o) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Wt = pl.wt; a.bias = pl.bias; a.kpad = pl.kpad; a.npad = pl.npad;
+    a.out0 = o.out0; a.out1 = o.out1; a.ldo0 = o.ldo0; a.ldo1 = o.ldo1;
+    a.split = o.split; a.nstore0 = o.nstore0; a.nstore1 = o.nstore1;
+    a.M = M; a.act = act;
+    return a;
+}
+static void add_block(GemmArgs& a, const float* p, int lda, int kp) {
+    a.A[a.nblocks] = p; a.lda[a.nblocks] = lda; a.kchunks[a.nblocks] = kp / 16;
+    a.nblocks++;
+}
+
+// layers [from, n_layers) of MLP m; `in`/`in_ld` feed layer `from` as one block
+static void run_mlp_tail(dsat_session* s, Launcher& L, int cls, int m, int from, const float* in, int in_ld,
+                         int rows, const OutSpec& final_out, const int* done) {
+    const auto& layers = s->w->mlp[m];
+    const int n = (int)layers.size();
+    const float* cur = in;
+    int cur_ld = in_ld;
+    for (int l = from; l < n; ++l) {
+        const bool last = l == n - 1;
+        float* dst = s->hid[m][l & 1];
+        OutSpec o = last ? final_out : single_out(dst, s->hid_ld[m], s->hid_ld[m]);
+        GemmArgs a = make_gemm(layers[l], rows, last ? 0 : 1, o);
+        add_block(a, cur, cur_ld, layers[l].kpad);
+        L.run(cls, [&] { launch_gemm(a, done, L.st); });
+        cur = dst;
+        cur_ld = s->hid_ld[m];
+    }
+}
+
+// ---- one denoising step: the launch sequence ------------------------------------------
+// SURVEY.md §2.3 R1-R18; reference lines cited at each launch.
+static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_exit, float* trace_logits,
+                         bool prof) {
+    const dsat_graph* g = s->g;
+    const dsat_weights* w = s->w;
+    const int N = g->N, C = g->C;
+    Launcher L{s, st, prof};
+    const int* done = early_exit ? &s->ctl->done : nullptr;
+
+    L.run(KC_MISC, [&] { launch_aux(s->aux, N, rounds, s->in_noisy, s->ctl, st); });     // :214-219, :239
+    L.run(KC_MISC, [&] { launch_labels(s->labels, N, s->ctl, st); });                    // :145
+    L.run(KC_MISC, [&] { launch_fill(s->V, 1.f, (int64_t)N * F, st); });                 // :148
+    L.run(KC_MISC, [&] { launch_fill(s->Cs, 1.f, (int64_t)C * F, st); });                // :141
+
+    for (int r = 0; r < rounds; ++r) {
+        const float* auxr = s->aux + (size_t)r * N * AUX_W;
+        // R2 + R6 first layers: variables_query.L0 and lit_mlp.L0 share the input v1 (:240, :252)
+        {
+            float* hq = s->hid[DSAT_MLP_VARIABLES_QUERY][0];
+            float* hl = s->hid[DSAT_MLP_LIT][0];
+            OutSpec o{hq, hl, s->hid_ld[0], s->hid_ld[1], w->q_hpad, w->q_hpad, s->hid_ld[1]};
+            GemmArgs a = make_gemm(w->ql1, N, 1, o);
+            add_block(a, s->V, F, F);
+            add_block(a, auxr, AUX_W, AUX_W);
+            L.run(KC_GEMM_QL1, [&] { launch_gemm(a, done, st); });
+        }
+        // R2 query = variables_query(v1)                                              (:240)
+        run_mlp_tail(s, L, KC_GEMM_Q, DSAT_MLP_VARIABLES_QUERY, 1, s->hid[0][0], s->hid_ld[0], N,
+                     single_out(s->q, F, F), done);
+        // R6 literals = [lit_mlp(v1)[:, :128]; [:, 128:]]                              (:252-254)
+        run_mlp_tail(s, L, KC_GEMM_LIT, DSAT_MLP_LIT, 1, s->hid[1][0], s->hid_ld[1], N,
+                     OutSpec{s->lits, s->lits + (size_t)N * F, F, F, F, F, F}, done);
+        // R3 + R5 + R7                                                                 (:241, :248, :255-256)
+        L.run(KC_CLAUSE_GATHER, [&] { launch_clause_gather(g, s->q, s->lits, s->closs4, 4.f, s->cmsg, done, st); });
+        // R8 clause_data = clause_mlp([clause_state, clause_messages, clauses_loss])   (:258-264)
+        {
+            const auto& layers = w->mlp[DSAT_MLP_CLAUSE];
+            const bool single = layers.size() == 1;
+            (void)single;
+            float* h0 = s->hid[DSAT_MLP_CLAUSE][0];
+            GemmArgs a = make_gemm(layers[0], C, 1, single_out(h0, s->hid_ld[2], s->hid_ld[2]));
+            add_block(a, s->Cs, F, F);
+            add_block(a, s->cmsg, F, F);
+            add_block(a, s->closs4, F, F);
+            L.run(KC_GEMM_CLAUSE, [&] { launch_gemm(a, done, st); });
+            run_mlp_tail(s, L, KC_GEMM_CLAUSE, DSAT_MLP_CLAUSE, 1, h0, s->hid_ld[2], C,
+                         OutSpec{s->vla, s->ncv, F, F, F, F, F}, done);
+        }
+        // R10 clause_state = 0.25*PairNorm(new_clause_value) + 0.1*clause_state (+ R18) (:265-266, :348)
+        L.run(KC_COLSUM, [&] { launch_colsum(g->cl_seg, g->G, s->nch_c, s->ncv, s->pc, done, st); });
+        L.run(KC_PAIRNORM, [&] {
+            launch_pairnorm_apply(g->cl_gid, g->cl_seg, C, s->nch_c, s->ncv, s->pc, s->Cs, 0.25f, 0.1f, 1,
+                                  s->Cs, nullptr, done, st);
+        });
+        // R4 + R11 (closs4 holds 4*closs; 0.25 restores the tape's operand exactly)     (:242-246, :269-273)
+        L.run(KC_LITERAL_GATHER, [&] {
+            launch_literal_gather(g, s->q, s->closs4, 0.25f, s->vla, s->grad, s->vl, done, st);
+        });
+        // R12 new_variables = update_gate([grad, v1, loss_pos, loss_neg])               (:277-278)
+        {
+            const auto& layers = w->mlp[DSAT_MLP_UPDATE_GATE];
+            float* h0 = s->hid[DSAT_MLP_UPDATE_GATE][0];
+            GemmArgs a = make_gemm(layers[0], N, 1, single_out(h0, s->hid_ld[3], s->hid_ld[3]));
+            add_block(a, s->grad, F, F);
+            add_block(a, s->V, F, F);
+            add_block(a, auxr, AUX_W, AUX_W);
+            add_block(a, s->vl, F, F);
+            add_block(a, s->vl + (size_t)N * F, F, F);
+            L.run(KC_GEMM_UPDATE, [&] { launch_gemm(a, done, st); });
+            run_mlp_tail(s, L, KC_GEMM_UPDATE, DSAT_MLP_UPDATE_GATE, 1, h0, s->hid_ld[3], N,
+                         single_out(s->newv, F, F), done);
+        }
+        // R13 variables = 0.25*PairNorm(new_variables) + 0.1*variables (+ R18)          (:279-280, :347)
+        L.run(KC_COLSUM, [&] { launch_colsum(g->var_seg, g->G, s->nch_v, s->newv, s->pv, done, st); });
+        L.run(KC_PAIRNORM, [&] {
+            launch_pairnorm_apply(g->var_gid, g->var_seg, N, s->nch_v, s->newv, s->pv, s->V, 0.25f, 0.1f, 1,
+                                  s->V, s->Vlog, done, st);
+        });
+        const bool last = r == rounds - 1;
+        if (early_exit || last || trace_logits) {
+            // R14 logits = variables_output(variables)                                 (:283)
+            const auto& layers = w->mlp[DSAT_MLP_VARIABLES_OUTPUT];
+            float* h0 = s->hid[DSAT_MLP_VARIABLES_OUTPUT][0];
+            GemmArgs a = make_gemm(layers[0], N, 1, single_out(h0, s->hid_ld[4], s->hid_ld[4]));
+            add_block(a, s->Vlog, F, F);
+            L.run(KC_GEMM_OUT, [&] { launch_gemm(a, done, st); });
+            run_mlp_tail(s, L, KC_GEMM_OUT, DSAT_MLP_VARIABLES_OUTPUT, 1, h0, s->hid_ld[4], N,
+                         single_out(s->logits, LOGIT_MAPS, LOGIT_MAPS), done);
+            if (trace_logits)
+                L.run(KC_MISC, [&] {
+                    launch_copy_if(s->logits, trace_logits + (size_t)r * N * LOGIT_MAPS, (int64_t)N * LOGIT_MAPS, done, st);
+                });
+        }
+        if (early_exit || last) {
+            // R15-R17: map selection and is_batch_sat                                    (:289-292, :317-338)
+            L.run(KC_SELECT, [&] {
+                launch_select(g, s->logits, s->labels, s->ctl, s->pgl, s->best, s->out_logits, s->assign,
+                              s->graph_unsat, st);
+            });
+            L.run(KC_SATCHECK, [&] { launch_sat_check(g, s->assign, s->graph_unsat, s->ctl, r, early_exit, st); });
+        }
+    }
+}
+
+// Run the step either eagerly or by replaying a captured graph.
+static int run_step(dsat_session* s, hipStream_t st, int rounds, int early_exit, float* trace_logits, int mode) {
+    const bool prof = s->profile != 0;
+    if (!s->use_graph || prof || trace_logits) {
+        if (mode == 1) launch_sample_pre(s->x0, s->x1, s->in_noisy, s->g->N, s->ctl, rounds, st);
+        enqueue_step(s, st, rounds, early_exit, trace_logits, prof);
+        if (mode == 1)
+            launch_sample_post(s->x0, s->x1, s->out_logits, s->g, s->graph_unsat, s->fixed_step, s->x_fixed,
+                               s->cum_acc, s->ctl, st);
+        DSAT_HIP(hipGetLastError());
+        return DSAT_OK;
+    }
+    auto key = std::make_tuple(rounds, early_exit, mode, 0);
+    auto it = s->graphs.find(key);
+    if (it == s->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        DSAT_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeThreadLocal));
+        if (mode == 1) launch_sample_pre(s->x0, s->x1, s->in_noisy, s->g->N, s->ctl, rounds, s->cap_stream);
+        enqueue_step(s, s->cap_stream, rounds, early_exit, nullptr, false);
+        if (mode == 1)
+            launch_sample_post(s->x0, s->x1, s->out_logits, s->g, s->graph_unsat, s->fixed_step, s->x_fixed,
+                               s->cum_acc, s->ctl, s->cap_stream);
+        DSAT_HIP(hipStreamEndCapture(s->cap_stream, &graph));
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__);
+        it = s->graphs.emplace(key, exec).first;
+    }
+    DSAT_HIP(hipGraphLaunch(it->second, st));
+    return DSAT_OK;
+}
+
+static Ctl base_ctl(float noise_scale, uint32_t step, int n_steps, int rounds, uint64_t seed) {
+    Ctl c;
+    memset(&c, 0, sizeof(c));
+    c.noise_scale = noise_scale; c.step = step; c.n_steps = n_steps; c.rounds = rounds; c.seed = seed;
+    c.steps_taken = rounds - 1;
+    return c;
+}
+
+extern "C" int dsat_diffusion_step(dsat_session* s, float noise_scale, const float* noisy_num,
+                                    const float* normal, const int32_t* labels, uint64_t seed,
+                                    uint32_t step_index, int32_t rounds, int32_t early_exit,
+                                    float* logits_out, float* logits_rounds_out, float* prediction_out,
+                                    int32_t* best_map_out, int32_t* steps_taken_out, void* stream) {
+    DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_diffusion_step: null session");
+    DSAT_REQUIRE(noisy_num != nullptr && prediction_out != nullptr, DSAT_E_INVALID,
+                 "dsat_diffusion_step: noisy_num and prediction_out are required");
+    DSAT_REQUIRE(rounds >= 1 && rounds <= s->max_rounds, DSAT_E_INVALID,
+                 "dsat_diffusion_step: rounds must be in [1, max_rounds of the session]");
+    DSAT_REQUIRE(std::isfinite(noise_scale), DSAT_E_INVALID, "dsat_diffusion_step: noise_scale is not finite");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = s->g->N;
+    DSAT_HIP(hipMemcpyAsync(s->in_noisy, noisy_num, N * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    Ctl c = base_ctl(noise_scale, step_index, 1, rounds, seed);
+    if (normal) {
+        DSAT_HIP(hipMemcpyAsync(s->in_normal, normal, (size_t)rounds * N * 4 * sizeof(float),
+                                hipMemcpyDeviceToDevice, st));
+        c.inj_normal = s->in_normal;
+    }
+    if (labels) {
+        DSAT_HIP(hipMemcpyAsync(s->in_labels, labels, N * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        c.inj_labels = s->in_labels;
+    }
+    launch_ctl_set(s->ctl, c, st);
+    int rc = run_step(s, st, rounds, early_exit ? 1 : 0, logits_rounds_out, 0);
+    if (rc != DSAT_OK) return rc;
+    DSAT_HIP(hipMemcpyAsync(prediction_out, s->out_logits, N * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (logits_out)
+        DSAT_HIP(hipMemcpyAsync(logits_out, s->logits, N * LOGIT_MAPS * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (best_map_out)
+        DSAT_HIP(hipMemcpyAsync(best_map_out, s->best, (size_t)s->g->G * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (steps_taken_out)
+        DSAT_HIP(hipMemcpyAsync(steps_taken_out, &s->ctl->steps_taken, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (s->profile) return collect_profile(s, st);
+    return DSAT_OK;
+}
+
+extern "C" int dsat_sample(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed, int32_t early_exit,
+                            const float* uniform, const float* normal, const int32_t* labels,
+                            uint8_t* assignment_out, uint8_t* solved_out, float* prediction_steps_out,
+                            float* solved_fraction_out, void* stream) {
+    DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_sample: null session");
+    DSAT_REQUIRE(n_steps >= 1 && n_steps <= (1 << 20), DSAT_E_INVALID, "dsat_sample: n_steps out of range");
+    DSAT_REQUIRE(rounds >= 1 && rounds <= s->max_rounds, DSAT_E_INVALID,
+                 "dsat_sample: rounds must be in [1, max_rounds of the session]");
+    DSAT_REQUIRE(assignment_out != nullptr, DSAT_E_INVALID, "dsat_sample: assignment_out is required");
+    hipStream_t st = (hipStream_t)stream;
+    const dsat_graph* g = s->g;
+    const size_t N = g->N;
+    Ctl c = base_ctl(1.f, 0, n_steps, rounds, seed);
+    c.inj_normal = normal; c.normal_step_stride = (int64_t)rounds * N * 4;
+    c.inj_labels = labels; c.labels_step_stride = (int64_t)N;
+    c.inj_uniform = uniform; c.uniform_step_stride = (int64_t)N;
+    c.pred_steps_out = prediction_steps_out;
+    launch_ctl_set(s->ctl, c, st);
+    launch_sample_init(s->x0, s->x1, g->N, s->fixed_step, s->cum_acc, g->G, s->ctl, st);
+    for (int t = 0; t < n_steps; ++t) {
+        int rc = run_step(s, st, rounds, early_exit ? 1 : 0, nullptr, 1);
+        if (rc != DSAT_OK) return rc;
+    }
+    launch_sample_final(s->out_logits, g, s->fixed_step, s->x_fixed, assignment_out, s->cum_acc, solved_out, st);
+    DSAT_HIP(hipGetLastError());
+    if (s->profile) {
+        int rc = collect_profile(s, st);
+        if (rc != DSAT_OK) return rc;
+    }
+    if (solved_fraction_out) {
+        std::vector<uint8_t> h(g->G);
+        DSAT_HIP(hipMemcpyAsync(h.data(), s->cum_acc, g->G, hipMemcpyDeviceToHost, st));
+        DSAT_HIP(hipStreamSynchronize(st));
+        double acc = 0;
+        for (uint8_t b : h) acc += b;
+        *solved_fraction_out = (float)(acc / (double)g->G);
+    }
+    return DSAT_OK;
+}
+
+// ============================================================================ single operators
+namespace dsat {
+__global__ void pack_blocks_kernel(const float* __restrict__ x, int in_dim, float* __restrict__ dst, int kpad,
+                                   int rows, int nb, int k0, int kp0, int k1, int kp1, int k2, int kp2, int k3,
+                                   int kp3, int k4, int kp4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * kpad) return;
+    const int row = (int)(i / kpad);
+    int col = (int)(i % kpad);
+    const int ks[5] = {k0, k1, k2, k3, k4}, kps[5] = {kp0, kp1, kp2, kp3, kp4};
+    int src = 0;
+    float v = 0.f;
+    for (int b = 0; b < nb; ++b) {
+        if (col < kps[b]) {
+            if (col < ks[b]) v = x[(size_t)row * in_dim + src + col];
+            break;
+        }
+        col -= kps[b];
+        src += ks[b];
+    }
+    dst[i] = v;
+}
+}  // namespace dsat
+
+extern "C" int dsat_op_mlp(dsat_session* s, int32_t mlp, const float* x, int32_t rows, float* y, void* stream) {
+    DSAT_REQUIRE(s && x && y, DSAT_E_INVALID, "dsat_op_mlp: null argument");
+    DSAT_REQUIRE(mlp >= 0 && mlp < DSAT_N_MLP, DSAT_E_INVALID, "dsat_op_mlp: mlp out of range");
+    const int cap = (mlp == DSAT_MLP_CLAUSE) ? std::max(s->g->C, 1) : s->g->N;
+    DSAT_REQUIRE(rows >= 0 && rows <= cap, DSAT_E_INVALID,
+                 "dsat_op_mlp: rows exceed the session's capacity for this MLP (N, or C for the clause MLP)");
+    if (rows == 0) return DSAT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const auto& layers = s->w->mlp[mlp];
+    auto blocks = first_layer_blocks(mlp);
+    int k[5] = {0, 0, 0, 0, 0}, kp[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < blocks.size(); ++i) { k[i] = blocks[i].k; kp[i] = blocks[i].kp; }
+    const int kpad = layers[0].kpad;
+    const int64_t n = (int64_t)rows * kpad;
+    hipLaunchKernelGGL(dsat::pack_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x,
+                       layers[0].in_dim, s->scratch, kpad, rows, (int)blocks.size(), k[0], kp[0], k[1], kp[1],
+                       k[2], kp[2], k[3], kp[3], k[4], kp[4]);
+    Launcher L{s, st, false};
+    float* h0 = s->hid[mlp][0];
+    const int od = layers.back().out_dim;
+    GemmArgs a = make_gemm(layers[0], rows, 1, single_out(h0, s->hid_ld[mlp], s->hid_ld[mlp]));
+    add_block(a, s->scratch, kpad, kpad);
+    launch_gemm(a, nullptr, st);
+    run_mlp_tail(s, L, KC_MISC, mlp, 1, h0, s->hid_ld[mlp], rows, single_out(y, od, od), nullptr);
+    DSAT_HIP(hipGetLastError());
+    return DSAT_OK;
+}
+
+extern "C" int dsat_op_clause_gather(dsat_session* s, const float* q, const float* lits, float* closs_out,
+                                      float* cmsg_out, void* stream) {
+    DSAT_REQUIRE(s && q && lits && closs_out && cmsg_out, DSAT_E_INVALID, "dsat_op_clause_gather: null argument");
+    launch_clause_gather(s->g, q, lits, closs_out, 1.f, cmsg_out, nullptr, (hipStream_t)stream);
+    DSAT_HIP(hipGetLastError());
+    return DSAT_OK;
+}
+
+extern "C" int dsat_op_literal_gather(dsat_session* s, const float* q, const float* closs, const float* vla,
+                                       float* grad_out, float* vloss_out, void* stream) {
+    DSAT_REQUIRE(s && q && closs && vla && grad_out && vloss_out, DSAT_E_INVALID,
+                 "dsat_op_literal_gather: null argument");
+    launch_literal_gather(s->g, q, closs, 1.f, vla, grad_out, vloss_out, nullptr, (hipStream_t)stream);
+    DSAT_HIP(hipGetLastError());
+    return DSAT_OK;
+}
+
+extern "C" int dsat_op_pair_norm(dsat_session* s, int32_t side, const float* x, float* y, void* stream) {
+    DSAT_REQUIRE(s && x && y, DSAT_E_INVALID, "dsat_op_pair_norm: null argument");
+    DSAT_REQUIRE(side == 0 || side == 1, DSAT_E_INVALID, "dsat_op_pair_norm: side must be 0 (variables) or 1 (clauses)");
+    const dsat_graph* g = s->g;
+    hipStream_t st = (hipStream_t)stream;
+    if (side == 0) {
+        launch_colsum(g->var_seg, g->G, s->nch_v, x, s->pv, nullptr, st);
+        launch_pairnorm_apply(g->var_gid, g->var_seg, g->N, s->nch_v, x, s->pv, nullptr, 1.f, 0.f, 0, y, nullptr,
+                              nullptr, st);
+    } else {
+        launch_colsum(g->cl_seg, g->G, s->nch_c, x, s->pc, nullptr, st);
+        launch_pairnorm_apply(g->cl_gid, g->cl_seg, g->C, s->nch_c, x, s->pc, nullptr, 1.f, 0.f, 0, y, nullptr,
+                              nullptr, st);
+    }
+    DSAT_HIP(hipGetLastError());
+    return DSAT_OK;
+}
+
+namespace dsat {
+__global__ void round_assign_kernel(const float* __restrict__ logits, uint8_t* __restrict__ assign,
+                                    int32_t* graph_unsat, int N, int G, Ctl* ctl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) assign[i] = (uint8_t)rintf(1.f / (1.f + expf(-logits[i])));
+    if (i < G) graph_unsat[i] = 0;
+    if (i == 0) { ctl->unsat_total = 0; ctl->ticket = 0; ctl->done = 0; }
+}
+}  // namespace dsat
+
+extern "C" int dsat_op_is_batch_sat(dsat_session* s, const float* logits, int32_t* is_sat_out, void* stream) {
+    DSAT_REQUIRE(s && logits && is_sat_out, DSAT_E_INVALID, "dsat_op_is_batch_sat: null argument");
+    const dsat_graph* g = s->g;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = std::max(g->N, g->G);
+    hipLaunchKernelGGL(dsat::round_assign_kernel, dim3((n + 255) / 256), dim3(256), 0, st, logits, s->assign,
+                       s->graph_unsat, g->N, g->G, s->ctl);
+    launch_sat_check(g, s->assign, s->graph_unsat, s->ctl, 0, 1, st);
+    int done = 0;
+    DSAT_HIP(hipMemcpyAsync(&done, &s->ctl->done, sizeof(int), hipMemcpyDeviceToHost, st));
+    DSAT_HIP(hipStreamSynchronize(st));
+    *is_sat_out = done;
+    return DSAT_OK;
+}
+
+extern "C" int dsat_op_rng(dsat_session* s, uint64_t seed, uint32_t step_index, int32_t rounds,
+                            float* normal_out, int32_t* labels_out, float* uniform_out, void* stream) {
+    DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_op_rng: null session");
+    DSAT_REQUIRE(rounds >= 0, DSAT_E_INVALID, "dsat_op_rng: negative rounds");
+    launch_rng(normal_out, labels_out, uniform_out, s->g->N, rounds, seed, step_index, (hipStream_t)stream);
+    DSAT_HIP(hipGetLastError());
+    return DSAT_OK;
+}

@@ -1,0 +1,163 @@
+// Internal structures shared by the kernels and the C-ABI layer (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/dsat.h"
+
+namespace dsat {
+
+constexpr int F = 128;        // feature_maps == query_maps (row = 512 B = 32 lanes x float4)
+constexpr int LOGIT_MAPS = 8;
+constexpr int AUX_W = 16;     // [normal(4) | noisy_num(2) | noise_scale(1) | denoised(2) | 0 x7]
+constexpr int AUX_USED = 9;   // 4 + 5 = the non-state columns of v1 (model/query_sat.py:239)
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define DSAT_HIP(call)                                                        \
+    do {                                                                      \
+        hipError_t _e = (call);                                               \
+        if (_e != hipSuccess) return ::dsat::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define DSAT_REQUIRE(cond, status, msg)            \
+    do {                                           \
+        if (!(cond)) {                             \
+            ::dsat::set_error(msg);                \
+            return (status);                       \
+        }                                          \
+    } while (0)
+
+// ---- packed dense layer -------------------------------------------------------
+struct PackedLayer {
+    int in_dim = 0, out_dim = 0;  // logical Keras dims
+    int kpad = 0;                 // padded K (sum of padded input blocks)
+    int npad = 0;                 // padded N (multiple of 32)
+    float* wt = nullptr;          // dev [npad][kpad] = kernel^T, zero padded
+    float* bias = nullptr;        // dev [npad]
+};
+
+// Input block of a concat-free GEMM: `k` logical columns at A (row stride lda),
+// occupying `kp` (multiple of 16) columns of the packed K axis.
+struct BlockSpec { int k; int kp; };
+
+}  // namespace dsat
+
+struct dsat_weights {
+    dsat_layout layout;
+    // [mlp][layer]
+    std::vector<std::vector<dsat::PackedLayer>> mlp;
+    // fused first layer of variables_query and lit_mlp (same input v1): N = q_h_pad + lit_h
+    dsat::PackedLayer ql1;
+    int q_hpad = 0, lit_h = 0;
+    float* slab = nullptr;  // one allocation behind every wt/bias pointer
+    size_t slab_bytes = 0;
+};
+
+struct dsat_graph {
+    int32_t N = 0, C = 0, G = 0;
+    int64_t E = 0;
+    int32_t max_clause_len = 0, max_lit_deg = 0;
+    // device arrays
+    int32_t* c_rowptr = nullptr;  // [C+1]
+    int32_t* c_lit = nullptr;     // [E] literal row in [0,2N)
+    int32_t* l_rowptr = nullptr;  // [2N+1]
+    int32_t* l_clause = nullptr;  // [E]
+    int32_t* var_gid = nullptr;   // [N]
+    int32_t* cl_gid = nullptr;    // [C]
+    int32_t* var_seg = nullptr;   // [G+1]
+    int32_t* cl_seg = nullptr;    // [G+1]
+    float* deg_w = nullptr;       // [2N]  rsqrt(max(deg_lit,1))           (query_sat.py:194)
+    float* vdeg_w = nullptr;      // [N]   4*rsqrt(max(deg_pos+deg_neg,1)) (:195)
+    float* rev_w = nullptr;       // [C]   rsqrt(max(clause_len,1))        (:197)
+    std::vector<int32_t> h_var_seg, h_cl_seg;
+};
+
+namespace dsat {
+
+// ---- GEMM ----------------------------------------------------------------------
+constexpr int GEMM_MAX_BLOCKS = 6;
+struct GemmArgs {
+    const float* A[GEMM_MAX_BLOCKS];
+    int lda[GEMM_MAX_BLOCKS];
+    int kchunks[GEMM_MAX_BLOCKS];   // 16-wide chunks per block
+    int nblocks;
+    const float* Wt;  // [npad][kpad]
+    const float* bias;
+    int kpad;
+    int npad;
+    float* out0;
+    float* out1;
+    int ldo0, ldo1;
+    int split;        // columns >= split go to out1 at (col - split)
+    int nstore0;      // store col < nstore0 in part 0
+    int nstore1;      // store (col-split) < nstore1 in part 1
+    int M;
+    int act;          // 1 = leaky_relu(0.2)
+};
+
+// Device-side control block of one session.  Everything that changes from one
+// denoising step to the next lives here, so that a captured hipGraph of a step can
+// be replayed unchanged (kernel arguments are frozen at capture).
+struct Ctl {
+    int done;          // set when is_batch_sat fired (early exit)
+    int steps_taken;   // last executed round
+    int unsat_total;   // scratch of the SAT check
+    int ticket;        // last-workgroup ticket of the SAT check
+    float noise_scale;
+    uint32_t step;     // denoising step index t (Philox counter word; injected-array row)
+    int32_t n_steps;   // T
+    int32_t rounds;
+    uint64_t seed;
+    const float* inj_normal;     // injected normal draws or nullptr (device Philox)
+    const int32_t* inj_labels;
+    const float* inj_uniform;
+    int64_t normal_step_stride;  // elements per step in the injected arrays (0 = no step axis)
+    int64_t labels_step_stride;
+    int64_t uniform_step_stride;
+    float* pred_steps_out;       // optional [T,N] record of every step's prediction
+};
+
+void launch_gemm(const GemmArgs& a, const int* done, hipStream_t st);
+
+// closs_out = closs_scale * exp(-S)
+void launch_clause_gather(const dsat_graph* g, const float* q, const float* lits,
+                          float* closs_out, float closs_scale, float* cmsg_out,
+                          const int* done, hipStream_t st);
+// `closs` holds closs/closs_scale' ; the kernel multiplies its sums by closs_scale
+void launch_literal_gather(const dsat_graph* g, const float* q, const float* closs,
+                           float closs_scale, const float* vla, float* grad_out,
+                           float* vloss_out, const int* done, hipStream_t st);
+int colsum_chunks(int G);
+void launch_colsum(const int32_t* seg, int G, int nch, const float* x, float* partial,
+                   const int* done, hipStream_t st);
+// v = scale*PairNorm(x) + keep*old ; y_logit (optional) = v ; y_carry = carry ? v*0.2+v*0.8 : v
+void launch_pairnorm_apply(const int32_t* gid, const int32_t* seg, int rows, int nch,
+                           const float* x, const float* partial, const float* old,
+                           float scale, float keep, int carry, float* y_carry, float* y_logit,
+                           const int* done, hipStream_t st);
+void launch_fill(float* p, float v, int64_t n, hipStream_t st);
+void launch_ctl_set(Ctl* dst, const Ctl& val, hipStream_t st);
+void launch_aux(float* aux, int N, int rounds, const float* noisy_num, const Ctl* ctl, hipStream_t st);
+void launch_labels(int32_t* labels, int N, const Ctl* ctl, hipStream_t st);
+void launch_rng(float* normal, int32_t* labels, float* uniform, int N, int rounds, uint64_t seed,
+                uint32_t step, hipStream_t st);
+void launch_select(const dsat_graph* g, const float* logits, const int32_t* labels, Ctl* ctl,
+                   float* pgl, int32_t* best, float* out_logits, uint8_t* assign,
+                   int32_t* graph_unsat, hipStream_t st);
+void launch_sat_check(const dsat_graph* g, const uint8_t* assign, int32_t* graph_unsat, Ctl* ctl,
+                      int round, int set_done, hipStream_t st);
+void launch_copy_if(const float* src, float* dst, int64_t n, const int* done, hipStream_t st);
+void launch_sample_init(float* x0, float* x1, int N, int32_t* fixed_step, uint8_t* cum_acc, int G,
+                        Ctl* ctl, hipStream_t st);
+void launch_sample_pre(float* x0, float* x1, float* noisy, int N, Ctl* ctl, int rounds, hipStream_t st);
+void launch_sample_post(float* x0, float* x1, const float* pred, const dsat_graph* g,
+                        const int32_t* graph_unsat, int32_t* fixed_step, float* x_fixed,
+                        uint8_t* cum_acc, Ctl* ctl, hipStream_t st);
+void launch_sample_final(const float* pred, const dsat_graph* g, const int32_t* fixed_step,
+                         const float* x_fixed, uint8_t* assignment, const uint8_t* cum_acc,
+                         uint8_t* solved, hipStream_t st);
+
+}  // namespace dsat

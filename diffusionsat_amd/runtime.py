@@ -1,0 +1,239 @@
+"""Python handles over the C-ABI objects (graph, weights, session).
+
+PyTorch is used only for device memory and streams: every tensor handed to the library
+is a contiguous CUDA(HIP) tensor whose ``data_ptr()`` crosses the boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .batch import Batch
+from .weights import WeightSet, to_blob
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=None, numel=None, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if numel is not None and t.numel() != numel:
+        raise ValueError("%s has %d elements, expected %d" % (name, t.numel(), numel))
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Graph:
+    """Device-resident CSR clause-literal graph of one batch (``dsat_graph``)."""
+
+    def __init__(self, batch: Batch):
+        lib = _lib.load()
+        self.batch = batch
+        self._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in
+                      (batch.clause_rowptr, batch.clause_lits, batch.var_graph_id, batch.clause_graph_id)]
+        h = C.c_void_p()
+        args = [a.ctypes.data_as(C.c_void_p) if a.size else None for a in self._keep]
+        _lib.check(lib.dsat_graph_create(args[0], args[1], args[2], args[3], batch.n_vars, batch.n_clauses,
+                                         batch.n_graphs, C.byref(h)))
+        self.handle = h
+        self.n_vars, self.n_clauses, self.n_graphs, self.n_edges = (
+            batch.n_vars, batch.n_clauses, batch.n_graphs, batch.n_edges)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().dsat_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Weights:
+    """Packed device copy of a weight set (``dsat_weights``)."""
+
+    def __init__(self, ws_or_blob, layout=None):
+        lib = _lib.load()
+        self.layout = layout or _lib.default_layout()
+        if isinstance(ws_or_blob, dict):
+            blob = to_blob(ws_or_blob, self.layout)
+        elif isinstance(ws_or_blob, torch.Tensor):
+            blob = ws_or_blob
+        else:
+            blob = np.ascontiguousarray(ws_or_blob, dtype=np.float32)
+        h = C.c_void_p()
+        if isinstance(blob, torch.Tensor):
+            if blob.dtype != torch.float32 or not blob.is_contiguous():
+                raise TypeError("weight blob tensor must be contiguous float32")
+            _lib.check(lib.dsat_weights_load(C.c_void_p(blob.data_ptr()), blob.numel(), C.byref(self.layout),
+                                             C.byref(h)))
+        else:
+            _lib.check(lib.dsat_weights_load(blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(self.layout),
+                                             C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().dsat_weights_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Session:
+    """Workspace + launch sequence for one (graph, weights) pair (``dsat_session``)."""
+
+    def __init__(self, graph: Graph, weights: Weights, max_rounds: int = 32, device="cuda:0"):
+        lib = _lib.load()
+        self.graph, self.weights = graph, weights
+        self.device = torch.device(device)
+        self.max_rounds = max_rounds
+        h = C.c_void_p()
+        _lib.check(lib.dsat_session_create(graph.handle, weights.handle, max_rounds, C.byref(h)))
+        self.handle = h
+
+    # -- the hot path ----------------------------------------------------------------
+    def diffusion_step(self, noise_scale: float, noisy_num: torch.Tensor, normal=None, labels=None,
+                       seed: int = 0, step_index: int = 0, rounds: int = 32, early_exit: bool = True,
+                       want_logits: bool = False, want_round_logits: bool = False):
+        lib = _lib.load()
+        n, g = self.graph.n_vars, self.graph.n_graphs
+        dev = self.device
+        pred = torch.empty(n, dtype=torch.float32, device=dev)
+        logits = torch.empty(n, 8, dtype=torch.float32, device=dev) if want_logits else None
+        rlog = torch.zeros(rounds, n, 8, dtype=torch.float32, device=dev) if want_round_logits else None
+        best = torch.empty(g, dtype=torch.int32, device=dev)
+        steps = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.dsat_diffusion_step(
+            self.handle, float(noise_scale), _ptr(noisy_num, torch.float32, 2 * n, "noisy_num"),
+            _ptr(normal, torch.float32, rounds * n * 4, "normal"), _ptr(labels, torch.int32, n, "labels"),
+            int(seed), int(step_index), int(rounds), int(bool(early_exit)),
+            _ptr(logits), _ptr(rlog), _ptr(pred), _ptr(best), _ptr(steps), _stream()))
+        return {"prediction": pred, "logits": logits, "round_logits": rlog, "best_map": best,
+                "steps_taken": steps}
+
+    def sample(self, n_steps: int = 32, rounds: int = 32, seed: int = 0, early_exit: bool = True,
+               uniform=None, normal=None, labels=None, want_predictions: bool = False,
+               want_solved_fraction: bool = True):
+        lib = _lib.load()
+        n, g = self.graph.n_vars, self.graph.n_graphs
+        dev = self.device
+        assign = torch.empty(n, dtype=torch.uint8, device=dev)
+        solved = torch.empty(g, dtype=torch.uint8, device=dev)
+        preds = torch.empty(n_steps, n, dtype=torch.float32, device=dev) if want_predictions else None
+        frac = C.c_float(-1.0)
+        _lib.check(lib.dsat_sample(
+            self.handle, int(n_steps), int(rounds), int(seed), int(bool(early_exit)),
+            _ptr(uniform, torch.float32, n_steps * n, "uniform"),
+            _ptr(normal, torch.float32, n_steps * rounds * n * 4, "normal"),
+            _ptr(labels, torch.int32, n_steps * n, "labels"),
+            _ptr(assign), _ptr(solved), _ptr(preds),
+            C.byref(frac) if want_solved_fraction else None, _stream()))
+        return {"assignment": assign, "solved": solved, "predictions": preds,
+                "solved_fraction": frac.value if want_solved_fraction else None}
+
+    # -- single operators ----------------------------------------------------------------
+    def op_mlp(self, mlp: int, x: torch.Tensor) -> torch.Tensor:
+        lib = _lib.load()
+        import ctypes
+        i, o = ctypes.c_int32(), ctypes.c_int32()
+        nl = self.weights.layout.n_layers[mlp]
+        _lib.check(lib.dsat_layout_layer_dims(C.byref(self.weights.layout), mlp, 0, C.byref(i), C.byref(o)))
+        in_dim = i.value
+        _lib.check(lib.dsat_layout_layer_dims(C.byref(self.weights.layout), mlp, nl - 1, C.byref(i), C.byref(o)))
+        out_dim = o.value
+        rows = x.shape[0]
+        y = torch.empty(rows, out_dim, dtype=torch.float32, device=self.device)
+        _lib.check(lib.dsat_op_mlp(self.handle, mlp, _ptr(x, torch.float32, rows * in_dim, "x"), rows, _ptr(y),
+                                   _stream()))
+        return y
+
+    def op_clause_gather(self, q, lits):
+        lib = _lib.load()
+        n, c = self.graph.n_vars, self.graph.n_clauses
+        closs = torch.empty(c, 128, dtype=torch.float32, device=self.device)
+        cmsg = torch.empty(c, 128, dtype=torch.float32, device=self.device)
+        _lib.check(lib.dsat_op_clause_gather(self.handle, _ptr(q, torch.float32, n * 128, "q"),
+                                             _ptr(lits, torch.float32, 2 * n * 128, "lits"),
+                                             _ptr(closs), _ptr(cmsg), _stream()))
+        return closs, cmsg
+
+    def op_literal_gather(self, q, closs, vla):
+        lib = _lib.load()
+        n, c = self.graph.n_vars, self.graph.n_clauses
+        grad = torch.empty(n, 128, dtype=torch.float32, device=self.device)
+        vloss = torch.empty(2 * n, 128, dtype=torch.float32, device=self.device)
+        _lib.check(lib.dsat_op_literal_gather(self.handle, _ptr(q, torch.float32, n * 128, "q"),
+                                              _ptr(closs, torch.float32, c * 128, "closs"),
+                                              _ptr(vla, torch.float32, c * 128, "vla"),
+                                              _ptr(grad), _ptr(vloss), _stream()))
+        return grad, vloss
+
+    def op_pair_norm(self, side: int, x):
+        lib = _lib.load()
+        rows = self.graph.n_vars if side == 0 else self.graph.n_clauses
+        y = torch.empty(rows, 128, dtype=torch.float32, device=self.device)
+        _lib.check(lib.dsat_op_pair_norm(self.handle, side, _ptr(x, torch.float32, rows * 128, "x"), _ptr(y),
+                                         _stream()))
+        return y
+
+    def op_is_batch_sat(self, logits) -> int:
+        lib = _lib.load()
+        out = C.c_int32(-1)
+        _lib.check(lib.dsat_op_is_batch_sat(self.handle, _ptr(logits, torch.float32, self.graph.n_vars, "logits"),
+                                            C.byref(out), _stream()))
+        return out.value
+
+    def op_rng(self, seed: int, step_index: int, rounds: int):
+        lib = _lib.load()
+        n = self.graph.n_vars
+        normal = torch.empty(rounds, n, 4, dtype=torch.float32, device=self.device)
+        labels = torch.empty(n, dtype=torch.int32, device=self.device)
+        uniform = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(lib.dsat_op_rng(self.handle, int(seed), int(step_index), int(rounds), _ptr(normal), _ptr(labels),
+                                   _ptr(uniform), _stream()))
+        return normal, labels, uniform
+
+    # -- knobs ------------------------------------------------------------------------
+    def set_graph_replay(self, enable: bool):
+        _lib.check(_lib.load().dsat_session_set_graph_replay(self.handle, int(enable)))
+
+    def set_profile(self, enable: bool):
+        _lib.check(_lib.load().dsat_session_set_profile(self.handle, int(enable)))
+
+    def profile(self):
+        lib = _lib.load()
+        cap = 32
+        names = (C.c_char_p * cap)()
+        us = (C.c_double * cap)()
+        cnt = (C.c_int64 * cap)()
+        n = lib.dsat_session_profile(self.handle, cap, names, us, cnt)
+        return {names[i].decode(): {"avg_us": us[i], "launches": cnt[i]} for i in range(n)}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().dsat_session_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,198 @@
+/*
+ * dsat.h -- C-ABI of the MI355X-native DiffusionSAT denoising-sampling hot path.
+ *
+ * This is the drop-in boundary (DESIGN.md "Boundary").  The reference has no FFI:
+ * its hot path is a Python method contract on TensorFlow tensors.  Each entry
+ * point below names the reference interface it replaces (paths relative to the
+ * reference repository).  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * Conventions
+ *   - every function returns 0 (DSAT_OK) or a negative dsat_status; the message
+ *     for the last failure on the calling thread is dsat_last_error().
+ *   - "dev" pointers are device (HBM) addresses owned by the caller (e.g. a torch
+ *     tensor's data_ptr()); "host" pointers are ordinary host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *     stream-ordered and do not synchronise unless they return a host scalar
+ *     (documented per function).
+ *   - one session per (graph, weights) pair per GPU; a session is not re-entrant.
+ *   - feature_maps = query_maps = 128 only (the reference's defaults,
+ *     model/query_sat.py:87-89); other widths return DSAT_E_UNSUPPORTED.
+ */
+#ifndef DSAT_H
+#define DSAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum dsat_status {
+    DSAT_OK = 0,
+    DSAT_E_INVALID = -1,      /* bad argument / malformed graph */
+    DSAT_E_UNSUPPORTED = -2,  /* layout the kernels are not built for */
+    DSAT_E_HIP = -3,          /* HIP runtime error (no device, OOM, launch failure) */
+    DSAT_E_STATE = -4         /* call order / session misuse */
+} dsat_status;
+
+typedef struct dsat_graph dsat_graph;
+typedef struct dsat_weights dsat_weights;
+typedef struct dsat_session dsat_session;
+
+/* Order of the five MLPs everywhere in this API. */
+enum { DSAT_MLP_VARIABLES_QUERY = 0, DSAT_MLP_LIT = 1, DSAT_MLP_CLAUSE = 2,
+       DSAT_MLP_UPDATE_GATE = 3, DSAT_MLP_VARIABLES_OUTPUT = 4, DSAT_N_MLP = 5 };
+
+/* Shape of the model, i.e. the arithmetic of QuerySAT.__init__
+ * (model/query_sat.py:86-126).  dsat_default_layout() fills the reference defaults:
+ * feature_maps=query_maps=128, logit_maps=8, layers {2,3,2,3,2},
+ * hidden {153,512,204,230,128}. */
+typedef struct dsat_layout {
+    int32_t feature_maps;
+    int32_t query_maps;
+    int32_t logit_maps;
+    int32_t n_layers[DSAT_N_MLP];
+    int32_t hidden[DSAT_N_MLP];
+} dsat_layout;
+
+const char* dsat_last_error(void);
+int32_t dsat_version(void);
+int dsat_default_layout(dsat_layout* out);
+/* Number of floats in a weight blob of this layout (see dsat_weights_load). */
+int64_t dsat_layout_blob_floats(const dsat_layout* layout);
+/* in/out widths of layer `layer` of MLP `mlp` (Keras Dense kernel is [in,out]). */
+int dsat_layout_layer_dims(const dsat_layout* layout, int32_t mlp, int32_t layer,
+                           int32_t* in_dim, int32_t* out_dim);
+
+/* ---- graph ---------------------------------------------------------------------
+ * Replaces SatSpecifics.create_adj_matrices (data/SatSpecifics.py:21-69) +
+ * compute_adj_indices (data/dimac.py:14-18): builds, on the device, the clause->
+ * literal CSR (A^T, `cl_adj_matrix`) and the literal->clause CSR (A, `adj_matrix`)
+ * of the batched formula, the degree weights of QuerySAT.loop's prologue
+ * (model/query_sat.py:193-197) and the per-graph segments that stand for
+ * `variables_graph` / `clauses_graph` (:206-211).
+ *
+ *   clause_rowptr [C+1]  host, int32, rowptr[0]=0, non-decreasing
+ *   clause_lits   [E]    host, int32, signed DIMACS literals in BATCH numbering:
+ *                        +v / -v with 1 <= v <= N (duplicates allowed; they add up,
+ *                        as duplicate COO entries do in tf.sparse.sparse_dense_matmul)
+ *   var_graph_id  [N]    host, int32 in [0,G), non-decreasing, every graph non-empty
+ *   clause_graph_id [C]  host, int32 in [0,G), non-decreasing
+ * Every literal of a clause must belong to the clause's graph (block-diagonal batch).
+ * The host arrays are only read during the call. */
+int dsat_graph_create(const int32_t* clause_rowptr, const int32_t* clause_lits,
+                      const int32_t* var_graph_id, const int32_t* clause_graph_id,
+                      int32_t n_vars, int32_t n_clauses, int32_t n_graphs, dsat_graph** out);
+void dsat_graph_destroy(dsat_graph* g);
+int dsat_graph_info(const dsat_graph* g, int32_t* n_vars, int32_t* n_clauses,
+                    int64_t* n_edges, int32_t* n_graphs);
+
+/* ---- weights -------------------------------------------------------------------
+ * Replaces the weight state of the five model/mlp.py MLPs that
+ * tf.train.Checkpoint.restore fills (satuniformity/DiffusionSampler.py:215-227).
+ * `blob` (host or device memory) is, for MLP 0..4 in the DSAT_MLP_* order and for
+ * each Dense layer in order: kernel[in,out] row-major (Keras layout) then bias[out].
+ * Kernels are re-packed on load (transposed, K/N padded with zeros) for the MFMA
+ * GEMM kernels. */
+int dsat_weights_load(const float* blob, int64_t n_floats, const dsat_layout* layout,
+                      dsat_weights** out);
+void dsat_weights_destroy(dsat_weights* w);
+
+/* ---- session -------------------------------------------------------------------
+ * Device workspace for one (graph, weights) pair: the state tensors of
+ * QuerySAT.call/loop (model/query_sat.py:141,148) and all intermediates.
+ * `max_rounds` bounds `rounds` of later calls (test_rounds, :88). */
+int dsat_session_create(const dsat_graph* g, const dsat_weights* w, int32_t max_rounds,
+                        dsat_session** out);
+void dsat_session_destroy(dsat_session* s);
+/* 1 (default) = replay each denoising step from a captured hipGraph; 0 = eager. */
+int dsat_session_set_graph_replay(dsat_session* s, int32_t enable);
+
+/* One denoising step = QuerySAT.diffusion_step (model/query_sat.py:467-481) ->
+ * call (:133-184) -> loop (:186-373) at inference, for `rounds` message-passing
+ * rounds.
+ *   noise_scale            :476 argument
+ *   noisy_num   dev [N,2]  :476 argument (x_noisy of DiffusionSampler.py:107)
+ *   normal      dev [rounds,N,4] or NULL.  The tf.random.normal([n_vars,4]) of
+ *               every round (:239), injected.  NULL = drawn on the device from
+ *               Philox4x32-10 keyed by (seed, step_index) (oracle/philox.py mirrors it).
+ *   labels      dev int32 [N] in {0,1} or NULL.  The random labels of :145
+ *               (labels=None at inference); NULL = device Philox.
+ *   early_exit  1 = stop at the first round whose selected assignment satisfies
+ *               every clause of the batch (is_batch_sat, :330-338; utils/sat.py:118-124);
+ *               0 = always run `rounds` rounds (fixed work, for throughput runs).
+ * Outputs (all optional except prediction_out):
+ *   logits_out        dev [N,8]         logits of the last executed round (:283)
+ *   logits_rounds_out dev [rounds,N,8]  logits of every executed round (parity tests)
+ *   prediction_out    dev [N]           "prediction" (:371-373, :480)
+ *   best_map_out      dev int32 [G]     argmin logit map per graph (:317)
+ *   steps_taken_out   dev int32 [1]     index of the last executed round (:478)
+ * Stream-ordered; does not synchronise. */
+int dsat_diffusion_step(dsat_session* s, float noise_scale, const float* noisy_num,
+                        const float* normal, const int32_t* labels,
+                        uint64_t seed, uint32_t step_index,
+                        int32_t rounds, int32_t early_exit,
+                        float* logits_out, float* logits_rounds_out, float* prediction_out,
+                        int32_t* best_map_out, int32_t* steps_taken_out, void* stream);
+
+/* T denoising steps around dsat_diffusion_step = diffusion()
+ * (satuniformity/DiffusionSampler.py:78-191) with use_baseline_sampling=True,
+ * self_supervised=False (:17-21), entirely on the device: randomized rounding
+ * (model/query_sat.py:55-60), the step, SATAccuracyTF.accuracy per graph
+ * (metrics/sat_metrics.py:60-85), reverse_distribution_step_theoretic (:29-37) and
+ * freeze-on-first-solution per graph (:154-170, :181-184).
+ *   uniform dev [T,N]        or NULL   noise of randomized_rounding_tf, injected
+ *   normal  dev [T,rounds,N,4] or NULL
+ *   labels  dev int32 [T,N]  or NULL   (NULL = device Philox keyed by seed)
+ * Outputs:
+ *   assignment_out dev uint8 [N]  final predictions (:181-184), 1 = True
+ *   solved_out     dev uint8 [G]  cum_accuracy per graph (:130)
+ *   prediction_steps_out dev [T,N] or NULL: "prediction" logits of every step
+ *   solved_fraction_out  host float* or NULL: mean(cum_accuracy) (:191); when not
+ *                        NULL the call synchronises the stream before returning. */
+int dsat_sample(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed,
+                int32_t early_exit, const float* uniform, const float* normal,
+                const int32_t* labels, uint8_t* assignment_out, uint8_t* solved_out,
+                float* prediction_steps_out, float* solved_fraction_out, void* stream);
+
+/* ---- single operators (parity tests and per-kernel roofline measurements) --------
+ * The layers the kernels sit behind, exposed one at a time.  All pointers dev. */
+
+/* MLP.call (model/mlp.py:42-50) of MLP `mlp` on x[rows, in_dim] -> y[rows, out_dim]. */
+int dsat_op_mlp(dsat_session* s, int32_t mlp, const float* x, int32_t rows, float* y,
+                void* stream);
+/* softplus_loss_adj (loss/sat.py:125-137) fused with the literal->clause message
+ * product (model/query_sat.py:255-256):
+ *   closs_out[C,128] = exp(-(A^T softplus([q;-q])));  cmsg_out[C,128] = (A^T lits)*rsqrt(len)
+ *   q dev [N,128], lits dev [2N,128]. */
+int dsat_op_clause_gather(dsat_session* s, const float* q, const float* lits,
+                          float* closs_out, float* cmsg_out, void* stream);
+/* Inner-tape gradient in closed form (model/query_sat.py:227-246) fused with the
+ * clause->literal message product (:269-273):
+ *   grad_out[N,128] = (-sig(q)*(A closs)[:N] + sig(-q)*(A closs)[N:]) * 4*rsqrt(deg_var)
+ *   vloss_out[2N,128] = (A vla) * rsqrt(deg_lit) */
+int dsat_op_literal_gather(dsat_session* s, const float* q, const float* closs,
+                           const float* vla, float* grad_out, float* vloss_out, void* stream);
+/* PairNorm.call with subtract_mean=True (layers/normalization.py:43-71) per graph:
+ * side 0 = variables [N,128], 1 = clauses [C,128]. y = PairNorm(x). */
+int dsat_op_pair_norm(dsat_session* s, int32_t side, const float* x, float* y, void* stream);
+/* is_batch_sat (utils/sat.py:118-124) of prediction logits[N]; result (0/1) to
+ * host `is_sat_out`; synchronises. */
+int dsat_op_is_batch_sat(dsat_session* s, const float* logits, int32_t* is_sat_out, void* stream);
+/* Philox draws as the device path makes them (normal [rounds,N,4]; labels [N];
+ * uniform [N]) for a given (seed, step_index); any output may be NULL. */
+int dsat_op_rng(dsat_session* s, uint64_t seed, uint32_t step_index, int32_t rounds,
+                float* normal_out, int32_t* labels_out, float* uniform_out, void* stream);
+
+/* Average device time in microseconds of the kernels of the last
+ * dsat_diffusion_step/dsat_sample call when profiling was enabled with
+ * dsat_session_set_profile(s, 1) (HIP events on the launch stream, eager mode).
+ * names/us_out have room for `cap` entries; returns the number of kernel classes. */
+int dsat_session_set_profile(dsat_session* s, int32_t enable);
+int dsat_session_profile(dsat_session* s, int32_t cap, const char** names, double* us_out,
+                         int64_t* launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSAT_H */
