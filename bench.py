@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the denoising-sampling hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one denoising step = one QuerySAT.diffusion_step of R=32 message-passing
+rounds over one 20k-node batch (BASELINE config 2: 31 distinct hard 3-SAT instances,
+n=100, m=428 -> N=3100 vars, C=13268 clauses, 19468 nodes), run inside the device-side
+sampler loop (randomized rounding -> step -> SAT check -> reverse step).  Inputs are
+resident in HBM before the timed region; the step runs with the reference's semantics
+(early exit armed, per-round logits / map selection / is_batch_sat every round), which
+with random-init weights never fires, so the work per step is fixed.
+
+For N>1 the driver launches one rank per GPU (torch.distributed.run); every rank owns
+its own batch (weak scaling), weights are broadcast from rank 0 over RCCL, and there
+is no communication in the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = vector fp32 peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def gemm_flops_per_round(n_vars, n_clauses):
+    """Algorithmic flops of the 12 Dense layers of one round."""
+    return 1_446_966 * n_vars + 261_120 * n_clauses
+
+
+def sparse_bytes_per_round(n_vars, n_clauses, n_edges, f=128):
+    """Unique-traffic bytes of the four sparse products of one round."""
+    return 4 * f * (7 * n_vars + 4 * n_clauses) + 16 * n_edges + 8 * (n_clauses + 1) + 8 * (2 * n_vars + 1)
+
+
+def cpu_baseline(instances, ws, rounds, budget_s=20.0):
+    """CPU restatement (oracle/querysat_torch.py), timed on this host's cores on a bounded
+    sample of the same workload: whole denoising steps of the same batch."""
+    import torch
+    from oracle import querysat_torch as QT
+    tb = QT.TorchBatch(instances)
+    tw = QT.to_torch_weights(ws)
+    rng = np.random.default_rng(0)
+    n = tb.n
+    noisy = np.stack([np.ones(n), np.zeros(n)], 1).astype(np.float32)
+    normal = rng.standard_normal((rounds, n, 4)).astype(np.float32)
+    labels = rng.integers(0, 2, n)
+    with torch.no_grad():
+        QT.diffusion_step(tw, tb, 0.5, noisy, normal[:2], labels, 2)      # warm-up: 2 rounds
+        done, t0 = 0, time.perf_counter()
+        while True:
+            QT.diffusion_step(tw, tb, 0.5, noisy, normal, labels, rounds)
+            done += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or done >= 8:
+                break
+    return {"value": done / el, "unit": "denoising-steps/s", "cores": int(torch.get_num_threads()),
+            "kind": "port",
+            "sample": "%d denoising steps (R=%d rounds) of the same config-2 batch, PyTorch-CPU fp32 restatement, "
+                      "early exit off, %.1f s" % (done, rounds, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--rounds", type=int, default=32)
+    ap.add_argument("--graphs", type=int, default=31, help="instances per batch (config 2: 31 x n=100)")
+    ap.add_argument("--vars", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="disable hipGraph replay")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from diffusionsat_amd import build, runtime, weights as W
+    from diffusionsat_amd.batch import make_batch
+    from diffusionsat_amd.instances import config2_instances
+    build.build()
+
+    # ---- inputs: one config-2 batch per rank (weak scaling), weights from rank 0 -------------
+    instances = config2_instances(args.graphs, args.vars, seed=2 + rank)
+    batch = make_batch(instances)
+    ws = W.glorot_weights(seed=0)
+    blob = torch.from_numpy(W.to_blob(ws)).to(dev)
+    if dist is not None:
+        if rank != 0:
+            blob.zero_()
+        dist.broadcast(blob, src=0)            # RCCL over xGMI; the only collective on the path
+    graph = runtime.Graph(batch)
+    wts = runtime.Weights(blob)
+    sess = runtime.Session(graph, wts, max_rounds=args.rounds, device=dev)
+    sess.set_graph_replay(not args.eager)
+
+    def run(n_steps, seed):
+        return sess.sample(n_steps, args.rounds, seed=seed, early_exit=True, want_solved_fraction=False)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(args.warmup, seed=1)
+    barrier()
+    t0 = time.perf_counter()
+    out = run(args.steps, seed=2)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    solved_fraction = float(out["solved"].float().mean().item())
+
+    result = None
+    if rank == 0:
+        n, c, e = batch.n_vars, batch.n_clauses, batch.n_edges
+        value = world * args.steps / elapsed
+        result = {
+            "metric": "denoising-steps/sec, 20k-node 3-SAT batch",
+            "value": value, "unit": "denoising-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "solved_fraction": solved_fraction,
+            "config": {"workload": "BASELINE config 2: %d planted hard 3-SAT instances n=%d m=%d per GPU "
+                                   "(N=%d vars, C=%d clauses, E=%d edges, %d nodes), R=%d rounds per denoising "
+                                   "step, T=%d steps, random-init Glorot weights, device Philox noise, early exit "
+                                   "armed (never fires)" % (batch.n_graphs, args.vars, len(instances[0][1]), n, c, e,
+                                                            batch.n_nodes, args.rounds, args.steps),
+                       "rounds": args.rounds, "nodes_per_gpu": batch.n_nodes, "parallelism": "batch-sharded x%d" % world,
+                       "hip_graph_replay": not args.eager},
+        }
+        # ---- per-kernel device times, live (HIP events on the launch stream, eager) -------------
+        if not args.no_profile:
+            sess.set_profile(True)
+            run(2, seed=3)
+            prof = sess.profile()
+            sess.set_profile(False)
+            steps_prof = 2
+            all_us = sum(v["avg_us"] * v["launches"] for v in prof.values()) / steps_prof
+            # algorithmic flops per launch of each fused round kernel (SURVEY.md §8d per-row MACs)
+            per_launch = {
+                "round_p1_var_query_lit": 2.0 * n * (40_545 + 463_360 + 17_408),   # query + lit + output MLPs
+                "round_p2_clause": 2.0 * c * 130_560,                               # clause MLP
+                "round_p3_var_update": 2.0 * n * 202_170,                           # update gate
+            }
+            kern_name = {"round_p1_var_query_lit": "round_p1_kernel", "round_p2_clause": "round_p2_kernel<4>",
+                         "round_p3_var_update": "round_p3_kernel"}
+            roofs = {}
+            for k, fl in per_launch.items():
+                if k in prof and prof[k]["launches"] > 0:
+                    us = prof[k]["avg_us"]
+                    ach = fl / (us * 1e-6) / 1e12
+                    roofs[k] = {"bound": "mfma", "kernel": kern_name[k], "achieved": ach,
+                                "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS,
+                                "traffic": None, "avg_launch_us": us,
+                                "launches_per_step": prof[k]["launches"] / steps_prof,
+                                "algorithmic_flops_per_launch": fl,
+                                "share_of_device_time": us * prof[k]["launches"] / steps_prof / all_us}
+            if roofs:
+                dom = max(roofs, key=lambda k: roofs[k]["share_of_device_time"])
+                result["roofline"] = roofs[dom]
+                result["roofline_kernels"] = roofs
+            else:   # per-layer path (DSAT_FUSED=0)
+                gemm = {k: v for k, v in prof.items() if k.startswith("gemm_") and v["launches"]}
+                gemm_us = sum(v["avg_us"] * v["launches"] for v in gemm.values()) / steps_prof
+                gemm_launches = sum(v["launches"] for v in gemm.values()) / steps_prof
+                flops_step = gemm_flops_per_round(n, c) * args.rounds
+                ach = flops_step / (gemm_us * 1e-6) / 1e12
+                result["roofline"] = {
+                    "bound": "mfma", "kernel": "gemm_f32_mfma_kernel", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                    "launches_per_step": gemm_launches, "avg_launch_us": gemm_us / gemm_launches,
+                    "algorithmic_flops_per_launch": flops_step / gemm_launches,
+                    "share_of_device_time": gemm_us / all_us}
+            result["kernel_time_us_per_step"] = {k: v["avg_us"] * v["launches"] / steps_prof
+                                                 for k, v in prof.items() if v["launches"]}
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(instances, ws, args.rounds)
+            result["cpu_baseline"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

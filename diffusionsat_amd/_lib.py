@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdsat.so")
+LIB_PATH = os.environ.get("DSAT_LIB") or os.path.join(HERE, "libdsat.so")  # DSAT_LIB: A/B builds of the same ABI
 
 N_MLP = 5
 MLP_NAMES = ("variables_query", "lit_mlp", "clause_mlp", "update_gate", "variables_output")
@@ -49,6 +49,8 @@ SIGNATURES = {
     "dsat_sample": (C.c_int, [_vp, _i32, _i32, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.POINTER(_f32), _vp]),
     "dsat_op_mlp": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp]),
+    "dsat_op_mlp_ex": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "dsat_bench_mlp": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_double), _vp]),
     "dsat_op_clause_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "dsat_op_literal_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dsat_op_pair_norm": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),

@@ -41,7 +41,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build diffusionsat_amd/libdsat.so")
     tmp = LIB + ".tmp.%d" % os.getpid()
+    # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs.  With AGPR accumulators hipcc
+    # (ROCm 7.2) shuffles them through v_accvgpr_read/write every loop iteration of the
+    # weight-streaming GEMM (236 copies per k-block ring turn), costing ~10 % of its time.
     cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1",
            "-Wall", "-Wno-unused-function", "-o", tmp] + _sources()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

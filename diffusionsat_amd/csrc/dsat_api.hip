@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "dsat_internal.h"
+#include "fused_common.h"
 
 namespace dsat {
 
@@ -349,7 +350,7 @@ extern "C" int dsat_weights_load(const float* blob, int64_t n_floats, const dsat
         staged.push_back(std::move(s));
     }
     size_t total = 0;
-    for (auto& s : staged) total += ((s.wt.size() + 63) & ~size_t(63)) + ((s.bias.size() + 63) & ~size_t(63));
+    for (auto& s : staged) total += 2 * ((s.wt.size() + 63) & ~size_t(63)) + ((s.bias.size() + 63) & ~size_t(63));
     w->slab_bytes = total * sizeof(float);
     DSAT_HIP(hipMalloc((void**)&w->slab, w->slab_bytes));
     size_t off = 0;
@@ -361,6 +362,21 @@ extern "C" int dsat_weights_load(const float* blob, int64_t n_floats, const dsat
         if (e == hipSuccess)
             e = hipMemcpy(s.dst->bias, s.bias.data(), s.bias.size() * sizeof(float), hipMemcpyHostToDevice);
         off += (s.bias.size() + 63) & ~size_t(63);
+        {   // fragment-ordered copy for the weight-streaming kernels
+            const PackedLayer& pl = *s.dst;
+            std::vector<float> wp(s.wt.size());
+            const int kb_n = pl.kpad / 16, nt = pl.npad / 16;
+            for (int t = 0; t < nt; ++t)
+                for (int kb = 0; kb < kb_n; ++kb)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 4; ++j)
+                            wp[(((size_t)t * kb_n + kb) * 64 + l) * 4 + j] =
+                                s.wt[(size_t)(t * 16 + (l & 15)) * pl.kpad + kb * 16 + 4 * (l >> 4) + j];
+            s.dst->wp = w->slab + off;
+            if (e == hipSuccess)
+                e = hipMemcpy(s.dst->wp, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice);
+            off += (wp.size() + 63) & ~size_t(63);
+        }
         if (e != hipSuccess) {
             dsat_weights_destroy(w.release());
             return hip_fail(e, "weights upload", __FILE__, __LINE__);
@@ -379,10 +395,11 @@ extern "C" void dsat_weights_destroy(dsat_weights* w) {
 // ============================================================================ session
 enum KernelClass { KC_GEMM_QL1 = 0, KC_GEMM_Q, KC_GEMM_LIT, KC_GEMM_CLAUSE, KC_GEMM_UPDATE, KC_GEMM_OUT,
                    KC_CLAUSE_GATHER, KC_LITERAL_GATHER, KC_COLSUM, KC_PAIRNORM, KC_SELECT, KC_SATCHECK,
-                   KC_MISC, KC_COUNT };
+                   KC_ROUND_P1, KC_ROUND_P2, KC_ROUND_P3, KC_SELECT_SAT, KC_MISC, KC_COUNT };
 static const char* kKernelClassNames[KC_COUNT] = {
     "gemm_query_lit_l1", "gemm_query", "gemm_lit", "gemm_clause", "gemm_update", "gemm_output",
-    "clause_gather", "literal_gather", "pairnorm_colsum", "pairnorm_apply", "select", "sat_check", "misc"};
+    "clause_gather", "literal_gather", "pairnorm_colsum", "pairnorm_apply", "select", "sat_check",
+    "round_p1_var_query_lit", "round_p2_clause", "round_p3_var_update", "select_sat", "misc"};
 
 struct dsat_session {
     const dsat_graph* g = nullptr;
@@ -401,6 +418,13 @@ struct dsat_session {
     float *in_noisy, *in_normal, *x0, *x1, *x_fixed, *scratch;
     Ctl* ctl;
     int nch_v = 1, nch_c = 1;
+    // fused round kernels (kernels_round.hip)
+    int use_fused = 1;
+    int p2_rb = 4;
+    float *sp = nullptr, *psum_v = nullptr, *psum_c = nullptr;
+    int32_t *vtile_seg = nullptr, *vgseg = nullptr, *ctile_seg = nullptr, *cgseg = nullptr;
+    std::vector<int32_t> h_vtile_seg, h_vgseg, h_ctile_seg, h_cgseg;
+    RoundArgs ra1, ra2, ra3;   // templates: per-launch fields (round, tail, ...) are patched in
     // graph replay
     int use_graph = 1;
     hipStream_t cap_stream = nullptr;
@@ -444,6 +468,125 @@ static void carve(dsat_session* s, Slab& sl) {
     for (int m = 0; m < DSAT_N_MLP; ++m) max_k = std::max<size_t>(max_k, s->w->mlp[m][0].kpad);
     s->scratch = sl.take<float>(std::max(N, C) * max_k);
     s->ctl = sl.take<Ctl>(1);
+    s->sp = sl.take<float>(2 * N * F);
+    s->psum_v = sl.take<float>(std::max<size_t>(s->h_vtile_seg.empty() ? 1 : s->h_vtile_seg.back(), 1) * F);
+    s->psum_c = sl.take<float>(std::max<size_t>(s->h_ctile_seg.empty() ? 1 : s->h_ctile_seg.back(), 1) * F);
+    s->vtile_seg = sl.take<int32_t>(s->h_vtile_seg.size());
+    s->vgseg = sl.take<int32_t>(s->h_vgseg.size());
+    s->ctile_seg = sl.take<int32_t>(s->h_ctile_seg.size());
+    s->cgseg = sl.take<int32_t>(s->h_cgseg.size());
+}
+
+// PairNorm partial-sum segments: one per (tile, graph with rows in that tile), in row order.
+static void build_segments(const std::vector<int32_t>& seg, int rows, int bm, std::vector<int32_t>& tile_seg,
+                           std::vector<int32_t>& gseg) {
+    const int G = (int)seg.size() - 1;
+    const int ntiles = (rows + bm - 1) / bm;
+    std::vector<int32_t> per_graph(G, 0);
+    tile_seg.assign(ntiles + 1, 0);
+    int g = 0, count = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int lo = t * bm, hi = std::min(rows, lo + bm);
+        tile_seg[t] = count;
+        while (g < G && seg[g + 1] <= lo) ++g;
+        for (int gg = g; gg < G && seg[gg] < hi; ++gg)
+            if (std::max(seg[gg], lo) < std::min(seg[gg + 1], hi)) { per_graph[gg]++; count++; }
+    }
+    tile_seg[ntiles] = count;
+    gseg.assign(G + 1, 0);
+    for (int i = 0; i < G; ++i) gseg[i + 1] = gseg[i] + per_graph[i];
+}
+
+static ChainSpec make_chain(const std::vector<PackedLayer>& layers, int rb) {
+    ChainSpec c;
+    memset(&c, 0, sizeof(c));
+    c.nlayers = (int)layers.size();
+    for (int l = 0; l < c.nlayers; ++l) {
+        c.L[l].wp = reinterpret_cast<const float4*>(layers[l].wp);
+        c.L[l].bias = layers[l].bias;
+        c.L[l].kblocks = layers[l].kblocks();
+        c.L[l].ntiles = layers[l].ntiles();
+        c.L[l].tpw = pick_tpw(c.L[l].ntiles, ROUND_NWAVES, max_tpw_for_rb(rb));
+    }
+    return c;
+}
+static int max_hidden_pad(const std::vector<PackedLayer>& layers) {
+    int m = 16;
+    for (size_t l = 0; l + 1 < layers.size(); ++l) m = std::max(m, layers[l].npad);
+    return m;
+}
+
+// Fill the three RoundArgs templates (graph, buffers, weights, LDS plan).  Returns false when
+// a tile does not fit the 160 KiB of LDS (then the per-layer path is used).
+static bool plan_round(dsat_session* s) {
+    const dsat_graph* g = s->g;
+    const dsat_weights* w = s->w;
+    RoundArgs a;
+    memset(&a, 0, sizeof(a));
+    a.c_rowptr = g->c_rowptr; a.c_lit = g->c_lit; a.l_rowptr = g->l_rowptr; a.l_clause = g->l_clause;
+    a.var_gid = g->var_gid; a.cl_gid = g->cl_gid; a.var_seg = g->var_seg; a.cl_seg = g->cl_seg;
+    a.deg_w = g->deg_w; a.vdeg_w = g->vdeg_w; a.rev_w = g->rev_w;
+    a.vtile_seg = s->vtile_seg; a.vgseg = s->vgseg; a.ctile_seg = s->ctile_seg; a.cgseg = s->cgseg;
+    a.N = g->N; a.C = g->C; a.G = g->G;
+    a.V = s->V; a.Cs = s->Cs; a.q = s->q; a.sp = s->sp; a.lits = s->lits; a.closs4 = s->closs4;
+    a.vla = s->vla; a.ncv = s->ncv; a.newv = s->newv; a.logits = s->logits;
+    a.psum_v = s->psum_v; a.psum_c = s->psum_c; a.noisy = s->in_noisy; a.ctl = s->ctl;
+    const int LDS = 40960;
+    bool ok = true;
+    {   // P1: [X 16x152 | Vlog 16x136 | A | B | mean]
+        RoundArgs& r = s->ra1;
+        r = a;
+        r.mq = make_chain(w->mlp[DSAT_MLP_VARIABLES_QUERY], 1);
+        r.mlit = make_chain(w->mlp[DSAT_MLP_LIT], 1);
+        r.mout = make_chain(w->mlp[DSAT_MLP_VARIABLES_OUTPUT], 1);
+        const int hid = std::max({max_hidden_pad(w->mlp[0]), max_hidden_pad(w->mlp[1]), max_hidden_pad(w->mlp[4])});
+        r.ld_x = F + AUX_W + 8;
+        r.ld_a = r.ld_b = hid + 8;
+        r.off_x = 0;
+        r.off_vlog = ROUND_BM_VAR * r.ld_x;
+        r.off_a = r.off_vlog + ROUND_BM_VAR * (F + 8);
+        r.off_b = r.off_a + ROUND_BM_VAR * r.ld_a;
+        r.off_mean = r.off_b + ROUND_BM_VAR * r.ld_b;
+        ok = ok && (r.off_mean + F <= LDS);
+    }
+    {   // P2: [X BMx392 | A | (B) | mean]
+        RoundArgs& r = s->ra2;
+        const auto& layers = w->mlp[DSAT_MLP_CLAUSE];
+        const int hid = max_hidden_pad(layers);
+        int rb = 4;
+        for (; rb >= 1; rb >>= 1) {
+            const int bm = 16 * rb;
+            const int need = bm * (3 * F + 8) + bm * (hid + 8) * (layers.size() > 2 ? 2 : 1) + F;
+            if (need <= LDS) break;
+        }
+        ok = ok && rb >= 1;
+        if (rb < 1) rb = 1;
+        s->p2_rb = rb;
+        r = a;
+        r.mcl = make_chain(layers, rb);
+        const int bm = 16 * rb;
+        r.ld_x = 3 * F + 8;
+        r.ld_a = r.ld_b = hid + 8;
+        r.off_x = 0;
+        r.off_a = bm * r.ld_x;
+        r.off_b = layers.size() > 2 ? r.off_a + bm * r.ld_a : r.off_a;
+        r.off_mean = r.off_b + bm * r.ld_b;
+    }
+    {   // P3: [X 16x536 | A | B]
+        RoundArgs& r = s->ra3;
+        const auto& layers = w->mlp[DSAT_MLP_UPDATE_GATE];
+        const int hid = max_hidden_pad(layers);
+        r = a;
+        r.mupd = make_chain(layers, 1);
+        r.ld_x = 4 * F + AUX_W + 8;
+        r.ld_a = r.ld_b = hid + 8;
+        r.off_x = 0;
+        r.off_a = ROUND_BM_VAR * r.ld_x;
+        r.off_b = r.off_a + ROUND_BM_VAR * r.ld_a;
+        r.off_mean = r.off_b + ROUND_BM_VAR * r.ld_b;
+        ok = ok && (r.off_mean <= LDS);
+    }
+    return ok;
 }
 
 extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, int32_t max_rounds,
@@ -454,6 +597,16 @@ extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, i
     DSAT_REQUIRE(max_rounds >= 1 && max_rounds <= 4096, DSAT_E_INVALID, "dsat_session_create: max_rounds out of range");
     std::unique_ptr<dsat_session> s(new dsat_session());
     s->g = g; s->w = w; s->max_rounds = max_rounds;
+    {   // tile sizes are fixed before the workspace is carved: P1/P3 16 rows, P2 16*p2_rb rows
+        const auto& cl = w->mlp[DSAT_MLP_CLAUSE];
+        const int hid = max_hidden_pad(cl);
+        int rb = 4;
+        for (; rb > 1; rb >>= 1)
+            if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + F <= 40960) break;
+        s->p2_rb = rb;
+        build_segments(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg);
+        build_segments(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg);
+    }
     Slab dry;
     carve(s.get(), dry);
     s->slab_bytes = dry.off + 256;
@@ -467,6 +620,21 @@ extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, i
     Slab real;
     real.base = s->slab; real.size = s->slab_bytes; real.dry = false;
     carve(s.get(), real);
+    {
+        auto cp = [](int32_t* d, const std::vector<int32_t>& h) {
+            return h.empty() ? hipSuccess : hipMemcpy(d, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        };
+        hipError_t e2 = cp(s->vtile_seg, s->h_vtile_seg);
+        if (e2 == hipSuccess) e2 = cp(s->vgseg, s->h_vgseg);
+        if (e2 == hipSuccess) e2 = cp(s->ctile_seg, s->h_ctile_seg);
+        if (e2 == hipSuccess) e2 = cp(s->cgseg, s->h_cgseg);
+        if (e2 != hipSuccess) {
+            (void)hipFree(s->slab);
+            return hip_fail(e2, "segment upload", __FILE__, __LINE__);
+        }
+    }
+    if (!plan_round(s.get())) s->use_fused = 0;
+    if (const char* ev = getenv("DSAT_FUSED")) s->use_fused = s->use_fused && atoi(ev) != 0;
     for (int i = 0; i < KC_COUNT; ++i) { s->prof_us[i] = 0; s->prof_n[i] = 0; }
     *out = s.release();
     return DSAT_OK;
@@ -682,25 +850,52 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
     }
 }
 
+// Fused launch sequence: per round P1 -> [S of the previous round] -> P2 -> P3, then the tail
+// P1 (last round's PairNorm + logits) and the last S.
+static void enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int early_exit, float* trace_logits,
+                               bool prof) {
+    Launcher L{s, st, prof};
+    RoundArgs a1 = s->ra1, a2 = s->ra2, a3 = s->ra3;
+    a1.check_done = a2.check_done = a3.check_done = early_exit;
+    a1.trace_logits = trace_logits;
+    for (int r = 0; r <= rounds; ++r) {
+        a1.round = r;
+        a1.tail = r == rounds;
+        L.run(KC_ROUND_P1, [&] { (void)launch_round_p1(a1, st); });
+        if (r > 0 && (early_exit || r == rounds))
+            L.run(KC_SELECT_SAT, [&] {
+                launch_select_sat(s->g, s->logits, s->ctl, s->pgl, s->best, s->out_logits, s->assign,
+                                  s->graph_unsat, r - 1, early_exit, st);
+            });
+        if (r == rounds) break;
+        a2.round = r;
+        a3.round = r;
+        L.run(KC_ROUND_P2, [&] { (void)launch_round_p2(a2, s->p2_rb, st); });
+        L.run(KC_ROUND_P3, [&] { (void)launch_round_p3(a3, st); });
+    }
+}
+
 // Run the step either eagerly or by replaying a captured graph.
 static int run_step(dsat_session* s, hipStream_t st, int rounds, int early_exit, float* trace_logits, int mode) {
     const bool prof = s->profile != 0;
     if (!s->use_graph || prof || trace_logits) {
         if (mode == 1) launch_sample_pre(s->x0, s->x1, s->in_noisy, s->g->N, s->ctl, rounds, st);
-        enqueue_step(s, st, rounds, early_exit, trace_logits, prof);
+        if (s->use_fused) enqueue_step_fused(s, st, rounds, early_exit, trace_logits, prof);
+        else enqueue_step(s, st, rounds, early_exit, trace_logits, prof);
         if (mode == 1)
             launch_sample_post(s->x0, s->x1, s->out_logits, s->g, s->graph_unsat, s->fixed_step, s->x_fixed,
                                s->cum_acc, s->ctl, st);
         DSAT_HIP(hipGetLastError());
         return DSAT_OK;
     }
-    auto key = std::make_tuple(rounds, early_exit, mode, 0);
+    auto key = std::make_tuple(rounds, early_exit, mode, s->use_fused);
     auto it = s->graphs.find(key);
     if (it == s->graphs.end()) {
         hipGraph_t graph = nullptr;
         DSAT_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeThreadLocal));
         if (mode == 1) launch_sample_pre(s->x0, s->x1, s->in_noisy, s->g->N, s->ctl, rounds, s->cap_stream);
-        enqueue_step(s, s->cap_stream, rounds, early_exit, nullptr, false);
+        if (s->use_fused) enqueue_step_fused(s, s->cap_stream, rounds, early_exit, nullptr, false);
+        else enqueue_step(s, s->cap_stream, rounds, early_exit, nullptr, false);
         if (mode == 1)
             launch_sample_post(s->x0, s->x1, s->out_logits, s->g, s->graph_unsat, s->fixed_step, s->x_fixed,
                                s->cum_acc, s->ctl, s->cap_stream);
@@ -850,6 +1045,92 @@ extern "C" int dsat_op_mlp(dsat_session* s, int32_t mlp, const float* x, int32_t
     launch_gemm(a, nullptr, st);
     run_mlp_tail(s, L, KC_MISC, mlp, 1, h0, s->hid_ld[mlp], rows, single_out(y, od, od), nullptr);
     DSAT_HIP(hipGetLastError());
+    return DSAT_OK;
+}
+
+static int op_mlp_fused(dsat_session* s, int mlp, const float* x, int rows, float* y, int rb, int nwaves,
+                        hipStream_t st, bool pack) {
+    const auto& layers = s->w->mlp[mlp];
+    auto blocks = first_layer_blocks(mlp);
+    int k[5] = {0, 0, 0, 0, 0}, kp[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < blocks.size(); ++i) { k[i] = blocks[i].k; kp[i] = blocks[i].kp; }
+    const int kpad = layers[0].kpad;
+    if (pack) {
+        const int64_t n = (int64_t)rows * kpad;
+        hipLaunchKernelGGL(dsat::pack_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x,
+                           layers[0].in_dim, s->scratch, kpad, rows, (int)blocks.size(), k[0], kp[0], k[1], kp[1],
+                           k[2], kp[2], k[3], kp[3], k[4], kp[4]);
+    }
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    int w0 = kpad, w1 = 16;   // widest tile held by each ping-pong buffer
+    a.nlayers = (int)layers.size();
+    for (int l = 0; l < a.nlayers; ++l) {
+        a.L[l].wp = reinterpret_cast<const float4*>(layers[l].wp);
+        a.L[l].bias = layers[l].bias;
+        a.L[l].kblocks = layers[l].kblocks();
+        a.L[l].ntiles = layers[l].ntiles();
+        a.L[l].tpw = pick_tpw(a.L[l].ntiles, nwaves, max_tpw_for_rb(rb));
+        if (l + 1 < a.nlayers) {
+            if (l & 1) w0 = std::max(w0, layers[l].npad); else w1 = std::max(w1, layers[l].npad);
+        }
+    }
+    a.x = s->scratch; a.kpad0 = kpad; a.ld_buf0 = w0 + 8; a.ld_buf1 = w1 + 8; a.rows = rows;
+    a.y = y; a.ldy = layers.back().out_dim; a.ncols_y = layers.back().out_dim;
+    DSAT_HIP(launch_chain(a, rb, nwaves, st));
+    return DSAT_OK;
+}
+
+extern "C" int dsat_op_mlp_ex(dsat_session* s, int32_t mlp, const float* x, int32_t rows, float* y,
+                              int32_t impl, int32_t rb, int32_t nwaves, void* stream) {
+    if (impl == 0) return dsat_op_mlp(s, mlp, x, rows, y, stream);
+    DSAT_REQUIRE(s && x && y, DSAT_E_INVALID, "dsat_op_mlp_ex: null argument");
+    DSAT_REQUIRE(mlp >= 0 && mlp < DSAT_N_MLP, DSAT_E_INVALID, "dsat_op_mlp_ex: mlp out of range");
+    const int cap = (mlp == DSAT_MLP_CLAUSE) ? std::max(s->g->C, 1) : s->g->N;
+    DSAT_REQUIRE(rows >= 0 && rows <= cap, DSAT_E_INVALID, "dsat_op_mlp_ex: rows exceed the session's capacity");
+    if (rows == 0) return DSAT_OK;
+    return op_mlp_fused(s, mlp, x, rows, y, rb, nwaves, (hipStream_t)stream, true);
+}
+
+// Average device time (us) of `iters` back-to-back runs of MLP `mlp` on `rows` rows (inputs:
+// whatever the session scratch holds), measured with HIP events on `stream`.
+extern "C" int dsat_bench_mlp(dsat_session* s, int32_t mlp, int32_t rows, int32_t impl, int32_t rb,
+                              int32_t nwaves, int32_t iters, double* avg_us, void* stream) {
+    DSAT_REQUIRE(s && avg_us && iters > 0, DSAT_E_INVALID, "dsat_bench_mlp: bad argument");
+    DSAT_REQUIRE(mlp >= 0 && mlp < DSAT_N_MLP, DSAT_E_INVALID, "dsat_bench_mlp: mlp out of range");
+    const int cap = (mlp == DSAT_MLP_CLAUSE) ? std::max(s->g->C, 1) : s->g->N;
+    DSAT_REQUIRE(rows > 0 && rows <= cap, DSAT_E_INVALID, "dsat_bench_mlp: rows exceed the session's capacity");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    DSAT_HIP(hipEventCreate(&e0));
+    DSAT_HIP(hipEventCreate(&e1));
+    const auto& layers = s->w->mlp[mlp];
+    const int od = layers.back().out_dim;
+    float* y = s->hid[mlp][1];   // hidden buffer is at least rows x out_dim? use newv/ncv-sized scratch instead
+    y = (mlp == DSAT_MLP_CLAUSE) ? s->hid[DSAT_MLP_CLAUSE][1] : s->hid[DSAT_MLP_LIT][1];
+    (void)od;
+    auto once = [&]() -> int {
+        if (impl == 0) {
+            Launcher L{s, st, false};
+            float* h0 = s->hid[mlp][0];
+            GemmArgs a = make_gemm(layers[0], rows, 1, single_out(h0, s->hid_ld[mlp], s->hid_ld[mlp]));
+            add_block(a, s->scratch, layers[0].kpad, layers[0].kpad);
+            launch_gemm(a, nullptr, st);
+            run_mlp_tail(s, L, KC_MISC, mlp, 1, h0, s->hid_ld[mlp], rows, single_out(y, od, od), nullptr);
+            return DSAT_OK;
+        }
+        return op_mlp_fused(s, mlp, nullptr, rows, y, rb, nwaves, st, false);
+    };
+    for (int i = 0; i < 3; ++i) { int rc = once(); if (rc != DSAT_OK) return rc; }
+    DSAT_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) { int rc = once(); if (rc != DSAT_OK) return rc; }
+    DSAT_HIP(hipEventRecord(e1, st));
+    DSAT_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    DSAT_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = (double)ms * 1e3 / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return DSAT_OK;
 }
 

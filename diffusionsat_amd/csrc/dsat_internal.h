@@ -37,6 +37,12 @@ struct PackedLayer {
     int npad = 0;                 // padded N (multiple of 32)
     float* wt = nullptr;          // dev [npad][kpad] = kernel^T, zero padded
     float* bias = nullptr;        // dev [npad]
+    // MFMA-fragment order for direct-to-register streaming (kernels_fused.hip):
+    // [npad/16 tiles][kpad/16 k-blocks][64 lanes][4]; lane l, element j holds
+    // W[k = 16*kb + 4*(l>>4) + j][n = 16*t + (l&15)]
+    float* wp = nullptr;
+    int ntiles() const { return npad / 16; }
+    int kblocks() const { return kpad / 16; }
 };
 
 // Input block of a concat-free GEMM: `k` logical columns at A (row stride lda),
@@ -121,6 +127,60 @@ struct Ctl {
 };
 
 void launch_gemm(const GemmArgs& a, const int* done, hipStream_t st);
+
+// ---- fused row-tile chain (kernels_chain.hip, fused_common.h) -------------------------
+struct ChainLayer {
+    const float4* wp;   // fragment-ordered weights
+    const float* bias;
+    int kblocks, ntiles, tpw;
+};
+struct ChainArgs {
+    ChainLayer L[4];
+    int nlayers;
+    const float* x;     // [rows][kpad0] packed input (blocks padded)
+    int kpad0;
+    int ld_buf0, ld_buf1;  // LDS row strides (floats, == 8 mod 16) of the two ping-pong activation tiles
+    int rows;
+    float* y;
+    int ldy, ncols_y;
+};
+hipError_t launch_chain(const ChainArgs& a, int rb, int nwaves, hipStream_t st);
+
+// ---- fused round kernels (kernels_round.hip) ---------------------------------------------
+// One message-passing round = three row-tile kernels (+ the select/SAT kernel):
+//   P1 var tile   : finish PairNorm of the previous round (R13), output MLP + logits of the
+//                   previous round (R14), then variables_query and lit_mlp chains (R2, R6)
+//   P2 clause tile: finish clause PairNorm of the previous round (R10), literal->clause
+//                   gather (R3, R5, R7), clause_mlp chain (R8, R9), column partial sums
+//   P3 var tile   : clause->literal gather (R4, R11), update_gate chain (R12), column sums
+struct ChainSpec { ChainLayer L[4]; int nlayers; };
+struct RoundArgs {
+    // graph
+    const int32_t *c_rowptr, *c_lit, *l_rowptr, *l_clause, *var_gid, *cl_gid, *var_seg, *cl_seg;
+    const float *deg_w, *vdeg_w, *rev_w;
+    const int32_t *vtile_seg, *vgseg, *ctile_seg, *cgseg;   // PairNorm partial-sum segments
+    int N, C, G;
+    // state and intermediates (HBM)
+    float *V, *Cs, *q, *sp, *lits, *closs4, *vla, *ncv, *newv, *logits, *psum_v, *psum_c;
+    const float* noisy;    // [N,2] noisy_num of this denoising step
+    Ctl* ctl;
+    float* trace_logits;   // optional [rounds,N,8]
+    int round;             // message-passing round this launch belongs to
+    int check_done;        // early exit armed: skip when ctl->done
+    int tail;              // P1 only: run the PairNorm + output-MLP part and stop
+    // weights
+    ChainSpec mq, mlit, mcl, mupd, mout;
+    // LDS plan (float offsets / row strides), filled by plan_round_lds
+    int ld_x, ld_a, ld_b, off_x, off_a, off_b, off_vlog, off_mean;
+};
+constexpr int ROUND_BM_VAR = 16;    // rows per variable-side tile
+constexpr int ROUND_NWAVES = 8;
+hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st);
+hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st);
+hipError_t launch_round_p3(const RoundArgs& a, hipStream_t st);
+void launch_select_sat(const dsat_graph* g, const float* logits, Ctl* ctl, float* pgl, int32_t* best,
+                       float* out_logits, uint8_t* assign, int32_t* graph_unsat, int round, int set_done,
+                       hipStream_t st);
 
 // closs_out = closs_scale * exp(-S)
 void launch_clause_gather(const dsat_graph* g, const float* q, const float* lits,

@@ -1,0 +1,247 @@
+// Building block of the fused row-tile kernels: one Dense layer whose input tile lives in
+// LDS and whose weights stream from L2/HBM straight into MFMA B fragments.
+//
+//   out[BM rows][N] = act( in[BM][K] @ W[K][N] + b ),  BM = 16*RB
+//
+// * v_mfma_f32_16x16x4_f32 (exact fp32).  Lane l of a wave holds, for a 16-deep k-block kb
+//   and 16-wide column tile t: A fragment = in[row l&15][16kb + 4(l>>4) .. +3] (one
+//   ds_read_b128) and B fragment = W[16kb + 4(l>>4) + j][16t + (l&15)], j=0..3 (one 16-B
+//   global load from the fragment-ordered copy `wp`, 1 KiB contiguous per wave).  MFMA
+//   step j multiplies k = {4g + j : g = 0..3}.
+// * Waves split N: wave w owns TPW consecutive column tiles per pass and keeps one
+//   accumulator per (row block, tile); the A fragment is reused across its tiles, so
+//   LDS traffic is 1/TPW of the MFMA operand traffic and each weight byte is used BM times.
+// * Weight loads are software-pipelined PD k-blocks ahead in registers (no LDS staging:
+//   no two waves share a B fragment).
+// * LDS rows are padded to ld = K + 8 (== 8 mod 16 floats): the ds_read_b128 lane groups
+//   then fall on distinct bank slots (checked exhaustively).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dsat {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int TPW>
+struct PrefetchDepth { static constexpr int value = TPW >= 8 ? 3 : TPW >= 6 ? 4 : TPW >= 3 ? 5 : TPW >= 2 ? 8 : 12; };
+
+// Weight-fragment loads are inline asm: hipcc (ROCm 7.2) otherwise proves that a register
+// prefetched PD iterations ahead equals a fresh load from the (read-only) weights and
+// re-materialises it right before the MFMA, which serialises L2 latency with the matrix
+// pipe.  An asm load is opaque, so the ring below stays a ring; completion is counted by
+// hand (cdna_hip_programming.md 5.7 item 1, form ii): every wait names the registers it
+// releases as "+v" operands, so no consumer can be scheduled above it.
+// 16-B load: per-lane 32-bit byte offset (VGPR) + wave-uniform 64-bit base (SGPR pair), so
+// the per-k-block address update is scalar arithmetic and costs no VALU issue slots.
+__device__ __forceinline__ void gload_b128(f32x4& dst, unsigned voff, const float4* sbase) {
+#ifdef DSAT_EXP_NOLOAD
+    dst = f32x4{1.f, 2.f, 3.f, (float)voff};
+#else
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_release(f32x4& first) {
+#ifdef DSAT_EXP_NOLOAD
+    asm volatile("" : "+v"(first));
+#else
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(first) : "n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void release(f32x4& r) { asm volatile("" : "+v"(r)); }
+
+// One k-block step of the ring: consume slot `p` (MFMAs in tile pairs), then refill it from
+// `sb` when REFILL.  Tiles are processed in pairs: 4 k-steps x 2 tiles x RB row blocks of
+// MFMAs, then the two refill loads of that pair -- issued only after the last MFMA that reads
+// the old fragment, so a ring slot keeps its physical registers and no copy of an in-flight
+// register can appear.  sched_barrier pins the interleave: one pair of 1-KiB loads per
+// 8*RB MFMAs instead of a burst of TPW loads at the end of the k-block.
+template <int RB, int TPW, bool REFILL>
+__device__ __forceinline__ void ring_step(const float4 (&a)[RB], f32x4 (&slot)[TPW], const unsigned (&voff)[TPW],
+                                          const float4* sb, f32x4 (&acc)[RB][TPW]) {
+#pragma unroll
+    for (int jp = 0; jp < TPW; jp += 2) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = jp; j < jp + 2 && j < TPW; ++j)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const float av = kk == 0 ? a[rb].x : kk == 1 ? a[rb].y : kk == 2 ? a[rb].z : a[rb].w;
+                    acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, slot[j][kk], acc[rb][j], 0, 0, 0);
+                }
+        if (REFILL) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = jp; j < jp + 2 && j < TPW; ++j) gload_b128(slot[j], voff[j], sb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// Accumulate tiles t0 .. t0+TPW-1 (tile indices clamped to ntiles-1 for the loads; the
+// caller discards clamped tiles) over all k-blocks.  acc must be zero-initialised.
+// Ring of PD k-blocks in registers with static indices: the main loop is unrolled PD times
+// and covers floor(kblocks/PD)*PD k-blocks, refilling each slot PD blocks ahead (index
+// clamped to the last block, so the number of loads in flight -- hence every vmcnt count --
+// is the same at every step); the remaining < PD blocks are already in the ring when the
+// main loop ends and are consumed by a peeled tail.  The A fragment of step s+1 is read
+// from LDS during step s.  The queue is drained before returning.
+template <int RB, int TPW>
+__device__ __forceinline__ void stream_gemm(const float* __restrict__ sIn, int ldin, int kblocks,
+                                            const float4* __restrict__ wp, int t0, int ntiles, int lane,
+                                            f32x4 (&acc)[RB][TPW]) {
+    constexpr int PD = PrefetchDepth<TPW>::value;
+    static_assert((PD - 1) * TPW <= 63, "vmcnt field is 6 bits");
+    unsigned voff[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = (t0 + j < ntiles) ? t0 + j : ntiles - 1;
+        voff[j] = (unsigned)((t * kblocks * 64 + lane) * 16);
+    }
+    const float* pa = sIn + (lane & 15) * ldin + 4 * (lane >> 4);
+    const int last = kblocks - 1;
+    f32x4 breg[PD][TPW];
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+        const int kb = p < last ? p : last;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) gload_b128(breg[p][j], voff[j], wp + (size_t)kb * 64);
+    }
+    float4 a_next[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#ifdef DSAT_EXP_NOLDS
+        a_next[rb] = make_float4(1.f, 2.f, 3.f, 4.f);
+#else
+        a_next[rb] = *reinterpret_cast<const float4*>(pa + rb * 16 * ldin);
+#endif
+    }
+    const int main_blocks = kblocks / PD * PD;
+    int kb = 0;
+    for (; kb < main_blocks; kb += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            float4 a[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a[rb] = a_next[rb];
+            {   // A fragment of the next step (address clamped to the last k-block)
+                const int k1 = kb + p + 1;
+                const int kc = k1 < last ? k1 : last;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+#ifdef DSAT_EXP_NOLDS
+                    a_next[rb] = make_float4(1.f + kc, 2.f, 3.f, 4.f);
+#else
+                    a_next[rb] = *reinterpret_cast<const float4*>(pa + rb * 16 * ldin + kc * 16);
+#endif
+                }
+            }
+            // slot p was requested PD steps ago; (PD-1)*TPW younger loads may stay in flight
+            wait_vmcnt_release<(PD - 1) * TPW>(breg[p][0]);
+#pragma unroll
+            for (int j = 1; j < TPW; ++j) release(breg[p][j]);
+#ifdef DSAT_EXP_SAMEADDR
+            const int kn = 0;
+#else
+            const int kn = kb + p + PD < last ? kb + p + PD : last;
+#endif
+            ring_step<RB, TPW, true>(a, breg[p], voff, wp + (size_t)kn * 64, acc);
+        }
+    }
+    // tail: blocks main_blocks .. kblocks-1 sit in slots 0 .. rem-1; nothing more is requested
+    wait_vmcnt_release<0>(breg[0][0]);
+#pragma unroll
+    for (int p = 0; p < PD; ++p)
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) release(breg[p][j]);
+    const int rem = kblocks - main_blocks;
+#pragma unroll
+    for (int p = 0; p + 1 < PD; ++p) {
+        if (p < rem) {
+            float4 a[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a[rb] = a_next[rb];
+            const int k1 = main_blocks + p + 1;
+            const int kc = k1 < last ? k1 : last;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+#ifdef DSAT_EXP_NOLDS
+                a_next[rb] = make_float4(1.f + kc, 2.f, 3.f, 4.f);
+#else
+                a_next[rb] = *reinterpret_cast<const float4*>(pa + rb * 16 * ldin + kc * 16);
+#endif
+            }
+            ring_step<RB, TPW, false>(a, breg[p], voff, wp, acc);
+        }
+    }
+}
+
+// One Dense layer for the whole workgroup.  `store(row, col, value)` receives every output
+// element (row in [0,16*RB), col in [0, 16*ntiles)) after bias and activation.
+template <int RB, int TPW, int NWAVES, typename Store>
+__device__ __forceinline__ void dense_layer_tpw(const float* __restrict__ sIn, int ldin, int kblocks,
+                                                const float4* __restrict__ wp, const float* __restrict__ bias,
+                                                int ntiles, int act, int wave, int lane, Store&& store) {
+    for (int base = 0; base < ntiles; base += NWAVES * TPW) {
+        const int t0 = base + wave * TPW;
+        if (t0 >= ntiles) continue;
+        f32x4 acc[RB][TPW];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) acc[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stream_gemm<RB, TPW>(sIn, ldin, kblocks, wp, t0, ntiles, lane, acc);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            if (t0 + j < ntiles) {
+                const int col = (t0 + j) * 16 + (lane & 15);
+                const float bv = bias[col];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[rb][j][i] + bv;
+                        if (act) v = v > 0.f ? v : 0.2f * v;
+                        store(rb * 16 + 4 * (lane >> 4) + i, col, v);
+                    }
+            }
+        }
+    }
+}
+
+// `tpw` (tiles per wave and pass, chosen on the host by pick_tpw) selects the register blocking.
+template <int RB, int NWAVES, typename Store>
+__device__ __forceinline__ void dense_layer(const float* __restrict__ sIn, int ldin, int kblocks,
+                                            const float4* __restrict__ wp, const float* __restrict__ bias,
+                                            int ntiles, int tpw, int act, int wave, int lane, Store&& store) {
+    // register budget: RB * TPW accumulators of 4 VGPRs + PD * TPW weight fragments in flight
+    constexpr int MAXT = RB == 1 ? 8 : RB == 2 ? 4 : 2;
+    if constexpr (MAXT >= 8) {
+        if (tpw == 8) { dense_layer_tpw<RB, 8, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store); return; }
+        if (tpw == 6) { dense_layer_tpw<RB, 6, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store); return; }
+    }
+    if constexpr (MAXT >= 4) {
+        if (tpw == 4) { dense_layer_tpw<RB, 4, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store); return; }
+        if (tpw == 3) { dense_layer_tpw<RB, 3, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store); return; }
+    }
+    if (tpw == 2) { dense_layer_tpw<RB, 2, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store); return; }
+    dense_layer_tpw<RB, 1, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store);
+}
+
+inline int max_tpw_for_rb(int rb) { return rb == 1 ? 8 : rb == 2 ? 4 : 2; }
+
+// Host: tiles per wave per pass minimising (passes x tpw), i.e. the busiest wave's work.
+inline int pick_tpw(int ntiles, int nwaves, int max_tpw) {
+    const int cands[6] = {8, 6, 4, 3, 2, 1};
+    int best = 1, best_cost = 1 << 30;
+    for (int c : cands) {
+        if (c > max_tpw) continue;
+        const int passes = (ntiles + nwaves * c - 1) / (nwaves * c);
+        const int cost = passes * c * 16 + passes;   // tile-times, then fewer passes
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+
+}  // namespace dsat

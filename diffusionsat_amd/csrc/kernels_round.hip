@@ -1,0 +1,509 @@
+// Fused message-passing round of QuerySAT.loop (model/query_sat.py:225-348): three row-tile
+// kernels per round plus one select/SAT kernel, instead of one launch per Dense layer /
+// sparse product / normalisation.  Every kernel keeps its tile's activations in LDS and
+// streams the weights through MFMA fragments (fused_common.h).
+//
+//   P1  variable tile (16 rows):  R13 (previous round's PairNorm, finished here from the
+//       per-tile column sums P3 left), R14 (previous round's logits), then R1-R2 and R6:
+//       query = variables_query(v1), literals = lit_mlp(v1); also softplus(+-query) for R3.
+//   P2  clause tile (16*RB rows): R10 (previous round's clause PairNorm), R3+R5+R7 (CSR
+//       gather of softplus / literal rows), R8-R9 clause_mlp, column sums of the new state.
+//   P3  variable tile (16 rows):  R4+R11 (CSR gather of clause loss / clause messages),
+//       R12 update_gate, column sums of the new state.
+//   S   one workgroup per graph:  R15-R17 map selection + is_batch_sat / per-graph SAT.
+//
+// PairNorm's per-graph mean crosses tiles.  Each producer tile writes the column sums of its
+// rows per graph it touches ("segments", ordered by row, so a graph's segments are contiguous);
+// the consumer adds a graph's segments in index order: deterministic, no atomics.
+#include "dsat_internal.h"
+#include "fused_common.h"
+#include "philox.h"
+
+namespace dsat {
+
+namespace {
+
+constexpr int NT = ROUND_NWAVES * 64;
+constexpr int LDS_FLOATS = 40960;   // 160 KiB static (see kernels_chain.hip on dynamic LDS)
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+// [normal(4) | noisy_num(2) | noise_scale | 0 ...] = the non-state columns of v1 (:214-219, :239)
+__device__ __forceinline__ void write_aux_row(float* dst, const Ctl* ctl, const float* noisy, int n, int N,
+                                              int round, bool valid) {
+    float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f, n0 = 0.f, n1 = 0.f, ns = 0.f;
+    if (valid) {
+        if (ctl->inj_normal != nullptr) {
+            const float4 v = ld4(ctl->inj_normal + ctl->normal_step_stride * ctl->step + ((size_t)round * N + n) * 4);
+            z0 = v.x; z1 = v.y; z2 = v.z; z3 = v.w;
+        } else {
+            u32x4 c = {(uint32_t)n, (uint32_t)round, ctl->step, (uint32_t)STREAM_NORMAL};
+            const u32x4 x = philox4x32_10(c, (uint32_t)ctl->seed, (uint32_t)(ctl->seed >> 32));
+            box_muller(x.x, x.y, z0, z1);
+            box_muller(x.z, x.w, z2, z3);
+        }
+        n0 = noisy[2 * n]; n1 = noisy[2 * n + 1]; ns = ctl->noise_scale;
+    }
+    st4(dst, make_float4(z0, z1, z2, z3));
+    st4(dst + 4, make_float4(n0, n1, ns, 0.f));
+    st4(dst + 8, make_float4(0.f, 0.f, 0.f, 0.f));
+    st4(dst + 12, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+// state = 0.25*PairNorm(x) + 0.1*state for the rows of one tile (layers/normalization.py:43-71,
+// query_sat.py:265-266 / :279-280), then the :347-348 mix for the copy that enters the next
+// round.  sState[.][0..127] receives the carried state, sLogit (optional) the pre-mix value.
+template <int BM>
+__device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const int32_t* __restrict__ gid,
+                                              const int32_t* __restrict__ seg, const int32_t* __restrict__ gseg,
+                                              const float* __restrict__ psum, const float* __restrict__ x,
+                                              float* __restrict__ state, bool first, float* sState, int ldS,
+                                              float* sLogit, int ldL, float* sMean, int tid) {
+    const int tile_hi = min(tile_lo + BM, rows);
+    const int sub = tid & 31, hw = tid >> 5;
+    // padding rows of the last tile: finite zeros for the MFMAs
+    for (int r = tile_hi - tile_lo + hw; r < BM; r += NT / 32) {
+        st4(sState + r * ldS + sub * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+        if (sLogit != nullptr) st4(sLogit + r * ldL + sub * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    if (first) {   // query_sat.py:141, :148: both states start as ones
+        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+        for (int r = tile_lo + hw; r < tile_hi; r += NT / 32) {
+            st4(sState + (r - tile_lo) * ldS + sub * 4, one);
+            st4(state + (size_t)r * F + sub * 4, one);
+        }
+        return;
+    }
+    const int g_first = gid[tile_lo], g_last = gid[tile_hi - 1];
+    for (int g = g_first; g <= g_last; ++g) {
+        const int s0 = seg[g], s1 = seg[g + 1];
+        const int lo = max(s0, tile_lo), hi = min(s1, tile_hi);
+        if (lo >= hi) continue;   // wave-uniform
+        if (tid < F) {
+            float m = 0.f;
+            for (int s = gseg[g]; s < gseg[g + 1]; ++s) m += psum[(size_t)s * F + tid];
+            sMean[tid] = m * (1.f / (float)(s1 - s0));
+        }
+        __syncthreads();
+        const float4 mean = ld4(sMean + sub * 4);
+        for (int r = lo + hw; r < hi; r += NT / 32) {
+            float4 v = ld4(x + (size_t)r * F + sub * 4);
+            v.x -= mean.x; v.y -= mean.y; v.z -= mean.z; v.w -= mean.w;
+            float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+            const float rs = 1.f / sqrtf(ss * (1.f / F) + 1e-6f);
+            const float4 o4 = ld4(state + (size_t)r * F + sub * 4);
+            float4 res;
+            res.x = v.x * rs * 0.25f + 0.1f * o4.x; res.y = v.y * rs * 0.25f + 0.1f * o4.y;
+            res.z = v.z * rs * 0.25f + 0.1f * o4.z; res.w = v.w * rs * 0.25f + 0.1f * o4.w;
+            if (sLogit != nullptr) st4(sLogit + (r - tile_lo) * ldL + sub * 4, res);
+            res.x = __fadd_rn(__fmul_rn(res.x, 0.2f), __fmul_rn(res.x, 0.8f));
+            res.y = __fadd_rn(__fmul_rn(res.y, 0.2f), __fmul_rn(res.y, 0.8f));
+            res.z = __fadd_rn(__fmul_rn(res.z, 0.2f), __fmul_rn(res.z, 0.8f));
+            res.w = __fadd_rn(__fmul_rn(res.w, 0.2f), __fmul_rn(res.w, 0.8f));
+            st4(sState + (r - tile_lo) * ldS + sub * 4, res);
+            st4(state + (size_t)r * F + sub * 4, res);
+        }
+        __syncthreads();
+    }
+}
+
+// Column sums of the tile's new rows (staged in LDS, ld = ldT), one segment per graph touched.
+template <int BM>
+__device__ __forceinline__ void tile_colsums(int tile_lo, int rows, const int32_t* __restrict__ gid,
+                                             const int32_t* __restrict__ seg, int seg_base,
+                                             float* __restrict__ psum, const float* sT, int ldT, int tid) {
+    const int tile_hi = min(tile_lo + BM, rows);
+    if (tile_hi <= tile_lo) return;
+    const int g_first = gid[tile_lo], g_last = gid[tile_hi - 1];
+    const int c = tid & (F - 1), lane_grp = tid / F, ngrp = NT / F;
+    int ord = 0;
+    for (int g = g_first; g <= g_last; ++g) {
+        const int lo = max(seg[g], tile_lo), hi = min(seg[g + 1], tile_hi);
+        if (lo >= hi) continue;
+        if (ord % ngrp == lane_grp) {
+            float s = 0.f;
+            for (int r = lo; r < hi; ++r) s += sT[(r - tile_lo) * ldT + c];
+            psum[(size_t)(seg_base + ord) * F + c] = s;
+        }
+        ++ord;
+    }
+}
+
+// Runs the layers of one MLP on the tile: input in LDS, hidden activations ping-pong between
+// bufA/bufB, the last layer goes to `final_store(row, col, v)`.  Ends with a barrier.
+template <int RB, typename Store>
+__device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, int ldin, float* bufA, int ldA,
+                                          float* bufB, int ldB, int wave, int lane, Store&& final_store) {
+    const float* in = sIn;
+    int ld_in = ldin;
+    for (int l = 0; l < m.nlayers; ++l) {
+        const ChainLayer& L = m.L[l];
+        if (l + 1 < m.nlayers) {
+            float* o = (l & 1) ? bufB : bufA;
+            const int ldo = (l & 1) ? ldB : ldA;
+            dense_layer<RB, ROUND_NWAVES>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
+                                          [=](int row, int col, float v) { o[row * ldo + col] = v; });
+            in = o;
+            ld_in = ldo;
+        } else {
+            dense_layer<RB, ROUND_NWAVES>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 0, wave, lane,
+                                          final_store);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------- P1
+__global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    if (a.check_done && a.ctl->done != 0) return;
+    constexpr int BM = ROUND_BM_VAR;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile_lo = blockIdx.x * BM;
+    const int N = a.N;
+    float* sX = smem + a.off_x;
+    float* sVlog = smem + a.off_vlog;
+    float* sA = smem + a.off_a;
+    float* sB = smem + a.off_b;
+    float* sMean = smem + a.off_mean;
+    const int ldx = a.ld_x, ldv = F + 8;
+
+    pairnorm_tile<BM>(tile_lo, N, a.var_gid, a.var_seg, a.vgseg, a.psum_v, a.newv, a.V, a.round == 0, sX, ldx,
+                      sVlog, ldv, sMean, tid);
+    if (tid < BM) {   // aux columns of v1 for this round
+        const int n = tile_lo + tid;
+        write_aux_row(sX + tid * ldx + F, a.ctl, a.noisy, n, N, a.round, n < N && !a.tail);
+    }
+    __syncthreads();
+
+    if (a.round > 0) {   // R14: logits of the previous round from the pre-mix state
+        float* lg = a.logits;
+        float* tr = a.trace_logits != nullptr ? a.trace_logits + (size_t)(a.round - 1) * N * LOGIT_MAPS : nullptr;
+        run_chain<1>(a.mout, sVlog, ldv, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float v) {
+            const int n = tile_lo + row;
+            if (n < N && col < LOGIT_MAPS) {
+                lg[(size_t)n * LOGIT_MAPS + col] = v;
+                if (tr != nullptr) tr[(size_t)n * LOGIT_MAPS + col] = v;
+            }
+        });
+    }
+    if (a.tail) return;
+
+    {   // R2: query = variables_query(v1); softplus(+-query) feeds the clause gather (loss/sat.py:132-133)
+        float* q = a.q;
+        float* sp = a.sp;
+        run_chain<1>(a.mq, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float v) {
+            const int n = tile_lo + row;
+            if (n < N && col < F) {
+                q[(size_t)n * F + col] = v;
+                sp[(size_t)n * F + col] = softplus_f(v);
+                sp[(size_t)(N + n) * F + col] = softplus_f(-v);
+            }
+        });
+    }
+    {   // R6: literals = [lit_mlp(v1)[:, :128] ; [:, 128:]]
+        float* lits = a.lits;
+        run_chain<1>(a.mlit, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float v) {
+            const int n = tile_lo + row;
+            if (n < N && col < 2 * F) lits[((size_t)(col < F ? n : N + n)) * F + (col & (F - 1))] = v;
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------- P2
+template <int RB>
+__global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    if (a.check_done && a.ctl->done != 0) return;
+    constexpr int BM = 16 * RB;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile_lo = blockIdx.x * BM;
+    const int C = a.C, N = a.N;
+    float* sX = smem + a.off_x;
+    float* sA = smem + a.off_a;
+    float* sB = smem + a.off_b;
+    float* sMean = smem + a.off_mean;
+    const int ldx = a.ld_x;
+
+    pairnorm_tile<BM>(tile_lo, C, a.cl_gid, a.cl_seg, a.cgseg, a.psum_c, a.ncv, a.Cs, a.round == 0, sX, ldx,
+                      nullptr, 0, sMean, tid);
+    // R3 + R5 + R7: one half-wave per clause row walks the clause's literals
+    {
+        const int sub = tid & 31, hw = tid >> 5;
+        for (int r = hw; r < BM; r += NT / 32) {
+            const int c = tile_lo + r;
+            float4 S = make_float4(0.f, 0.f, 0.f, 0.f), M = S;
+            float rw = 0.f;
+            if (c < C) {
+                const int e0 = a.c_rowptr[c], e1 = a.c_rowptr[c + 1];
+                rw = a.rev_w[c];
+                for (int e = e0; e < e1; e += 4) {
+                    int l[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) l[j] = (e + j < e1) ? a.c_lit[e + j] : -1;
+                    float4 sv[4], lv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (l[j] >= 0) {
+                            sv[j] = ld4(a.sp + (size_t)l[j] * F + sub * 4);
+                            lv[j] = ld4(a.lits + (size_t)l[j] * F + sub * 4);
+                        }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (l[j] >= 0) {
+                            S.x += sv[j].x; S.y += sv[j].y; S.z += sv[j].z; S.w += sv[j].w;
+                            M.x += lv[j].x; M.y += lv[j].y; M.z += lv[j].z; M.w += lv[j].w;
+                        }
+                }
+            }
+            float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C) {
+                cl = make_float4(4.f * expf(-S.x), 4.f * expf(-S.y), 4.f * expf(-S.z), 4.f * expf(-S.w));
+                st4(a.closs4 + (size_t)c * F + sub * 4, cl);
+            }
+            st4(sX + r * ldx + F + sub * 4, make_float4(M.x * rw, M.y * rw, M.z * rw, M.w * rw));
+            st4(sX + r * ldx + 2 * F + sub * 4, cl);
+        }
+    }
+    __syncthreads();
+    {   // R8-R9: clause_data = clause_mlp([clause_state, clause_messages, clauses_loss])
+        float* vla = a.vla;
+        float* ncv = a.ncv;
+        float* stage = sX;   // the input tile is dead once layer 0 has run
+        const int lds = F + 8;
+        run_chain<RB>(a.mcl, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float v) {
+            const int c = tile_lo + row;
+            if (col < F) {
+                if (c < C) vla[(size_t)c * F + col] = v;
+            } else if (col < 2 * F) {
+                stage[row * lds + (col - F)] = v;
+                if (c < C) ncv[(size_t)c * F + (col - F)] = v;
+            }
+        });
+        tile_colsums<BM>(tile_lo, C, a.cl_gid, a.cl_seg, a.ctile_seg[blockIdx.x], a.psum_c, stage, lds, tid);
+    }
+    (void)N;
+}
+
+// ------------------------------------------------------------------------------------- P3
+__global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    if (a.check_done && a.ctl->done != 0) return;
+    constexpr int BM = ROUND_BM_VAR;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile_lo = blockIdx.x * BM;
+    const int N = a.N;
+    float* sX = smem + a.off_x;
+    float* sA = smem + a.off_a;
+    float* sB = smem + a.off_b;
+    const int ldx = a.ld_x;
+    // unit = [variables_grad | variables | aux | loss_pos | loss_neg]        (query_sat.py:277)
+    constexpr int OFF_V = F, OFF_AUX = 2 * F, OFF_POS = 2 * F + AUX_W, OFF_NEG = 3 * F + AUX_W;
+    {   // R4 + R11: one wave per variable, half 0 = literal +v, half 1 = literal -v
+        const int sub = lane & 31, half = lane >> 5;
+        for (int r = wave; r < BM; r += ROUND_NWAVES) {
+            const int v = tile_lo + r;
+            float4 M = make_float4(0.f, 0.f, 0.f, 0.f), VL = M;
+            float dw = 0.f;
+            if (v < N) {
+                const int lit = v + half * N;
+                const int e0 = a.l_rowptr[lit], e1 = a.l_rowptr[lit + 1];
+                dw = a.deg_w[lit];
+                for (int e = e0; e < e1; e += 4) {
+                    int ci[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ci[j] = (e + j < e1) ? a.l_clause[e + j] : -1;
+                    float4 cv[4], vv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ci[j] >= 0) {
+                            cv[j] = ld4(a.closs4 + (size_t)ci[j] * F + sub * 4);
+                            vv[j] = ld4(a.vla + (size_t)ci[j] * F + sub * 4);
+                        }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ci[j] >= 0) {
+                            M.x += cv[j].x; M.y += cv[j].y; M.z += cv[j].z; M.w += cv[j].w;
+                            VL.x += vv[j].x; VL.y += vv[j].y; VL.z += vv[j].z; VL.w += vv[j].w;
+                        }
+                }
+            }
+            st4(sX + r * ldx + (half ? OFF_NEG : OFF_POS) + sub * 4,
+                make_float4(VL.x * dw, VL.y * dw, VL.z * dw, VL.w * dw));
+            float4 Mo;
+            Mo.x = __shfl_xor(M.x, 32); Mo.y = __shfl_xor(M.y, 32);
+            Mo.z = __shfl_xor(M.z, 32); Mo.w = __shfl_xor(M.w, 32);
+            if (half == 0) {   // closed form of the inner tape; closs4 = 4*closs, 0.25 is exact
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (v < N) {
+                    const float4 qv = ld4(a.q + (size_t)v * F + sub * 4);
+                    const float vw = a.vdeg_w[v];
+                    g.x = (-sigmoid_f(qv.x) * (M.x * 0.25f) + sigmoid_f(-qv.x) * (Mo.x * 0.25f)) * vw;
+                    g.y = (-sigmoid_f(qv.y) * (M.y * 0.25f) + sigmoid_f(-qv.y) * (Mo.y * 0.25f)) * vw;
+                    g.z = (-sigmoid_f(qv.z) * (M.z * 0.25f) + sigmoid_f(-qv.z) * (Mo.z * 0.25f)) * vw;
+                    g.w = (-sigmoid_f(qv.w) * (M.w * 0.25f) + sigmoid_f(-qv.w) * (Mo.w * 0.25f)) * vw;
+                }
+                st4(sX + r * ldx + sub * 4, g);
+            } else {
+                float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (v < N) vv = ld4(a.V + (size_t)v * F + sub * 4);
+                st4(sX + r * ldx + OFF_V + sub * 4, vv);
+            }
+        }
+        if (tid < BM) {
+            const int n = tile_lo + tid;
+            write_aux_row(sX + tid * ldx + OFF_AUX, a.ctl, a.noisy, n, N, a.round, n < N);
+        }
+    }
+    __syncthreads();
+    {   // R12: new_variables = update_gate(unit)
+        float* newv = a.newv;
+        float* stage = sX;
+        const int lds = F + 8;
+        run_chain<1>(a.mupd, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float v) {
+            const int n = tile_lo + row;
+            if (col < F) {
+                stage[row * lds + col] = v;
+                if (n < N) newv[(size_t)n * F + col] = v;
+            }
+        });
+        tile_colsums<BM>(tile_lo, N, a.var_gid, a.var_seg, a.vtile_seg[blockIdx.x], a.psum_v, stage, lds, tid);
+    }
+}
+
+// ------------------------------------------------------------------------------------- S
+// R15-R17 per graph: Bernoulli-KL loss of every logit map against the (random) labels
+// (query_sat.py:40-53, :289-292), argmin map (:317), selected logits (:328-329), rounded
+// assignment, then the SAT check of the graph's clauses (utils/sat.py:118-124;
+// metrics/sat_metrics.py:60-85).  The last workgroup publishes done / steps_taken.
+__device__ __forceinline__ float bern_kl(float a, float b) {
+    return a * (logf(a) - logf(b)) + (1.f - a) * (log1pf(-a) - log1pf(-b));
+}
+
+__global__ __launch_bounds__(256) void select_sat_kernel(
+    const int32_t* __restrict__ vseg, const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ c_lit, const float* __restrict__ logits, Ctl* __restrict__ ctl,
+    float* __restrict__ pgl, int32_t* __restrict__ best, float* __restrict__ out_logits,
+    uint8_t* __restrict__ assign, int32_t* __restrict__ graph_unsat, int N, int round, int set_done) {
+    if (set_done && ctl->done != 0) return;
+    __shared__ float red[256][LOGIT_MAPS + 1];
+    __shared__ int s_best, s_unsat;
+    const int g = blockIdx.x;
+    const int v0 = vseg[g], v1 = vseg[g + 1];
+    const float t = powf(ctl->noise_scale, 0.5f);
+    const float tl = fminf(t + 0.01f, 1.f);
+    const float norm = bern_kl(tl * 0.5f, 0.5f) + 1e-4f;
+    float acc[LOGIT_MAPS];
+#pragma unroll
+    for (int k = 0; k < LOGIT_MAPS; ++k) acc[k] = 0.f;
+    for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+        int label;
+        if (ctl->inj_labels != nullptr) {
+            label = ctl->inj_labels[ctl->labels_step_stride * ctl->step + v];
+        } else {
+            u32x4 c = {(uint32_t)v, 0u, ctl->step, (uint32_t)STREAM_LABELS};
+            label = (int)(philox4x32_10(c, (uint32_t)ctl->seed, (uint32_t)(ctl->seed >> 32)).x & 1u);
+        }
+        const float a = (float)label * (1.f - tl) + tl * 0.5f;
+        const float4 l0 = ld4(logits + (size_t)v * LOGIT_MAPS);
+        const float4 l1 = ld4(logits + (size_t)v * LOGIT_MAPS + 4);
+        const float lg[LOGIT_MAPS] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+        for (int k = 0; k < LOGIT_MAPS; ++k) {
+            const float b = sigmoid_f(lg[k]) * (1.f - t) + t * 0.5f;
+            acc[k] += bern_kl(a, b) / norm;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LOGIT_MAPS; ++k) red[threadIdx.x][k] = acc[k];
+    if (threadIdx.x == 0) s_unsat = 0;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < LOGIT_MAPS; ++k) red[threadIdx.x][k] += red[threadIdx.x + s][k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float inv = 1.f / (float)(v1 - v0);
+        int bi = 0;
+        float bv = red[0][0] * inv;
+        pgl[g * LOGIT_MAPS] = bv;
+        for (int k = 1; k < LOGIT_MAPS; ++k) {
+            const float x = red[0][k] * inv;
+            pgl[g * LOGIT_MAPS + k] = x;
+            if (x < bv) { bv = x; bi = k; }   // first minimum wins, as TF's CPU ArgMin
+        }
+        best[g] = bi;
+        s_best = bi;
+    }
+    __syncthreads();
+    const int bi = s_best;
+    for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+        const float x = logits[(size_t)v * LOGIT_MAPS + bi];
+        out_logits[v] = x;
+        assign[v] = (uint8_t)rintf(sigmoid_f(x));   // tf.round(tf.sigmoid(.)), half-to-even
+    }
+    __syncthreads();   // this workgroup's assign[] stores are visible to its own loads (same CU L1)
+    int unsat = 0;
+    for (int c = cseg[g] + threadIdx.x; c < cseg[g + 1]; c += 256) {
+        bool sat = false;
+        for (int e = rowptr[c]; e < rowptr[c + 1]; ++e) {
+            const int l = c_lit[e];
+            sat = sat || (l < N ? (assign[l] != 0) : (assign[l - N] == 0));
+        }
+        unsat += sat ? 0 : 1;
+    }
+    if (unsat) atomicAdd(&s_unsat, unsat);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        graph_unsat[g] = s_unsat;
+        if (s_unsat) atomicAdd(&ctl->unsat_total, s_unsat);
+        __threadfence();
+        const int tk = atomicAdd(&ctl->ticket, 1);
+        if (tk == (int)gridDim.x - 1) {
+            const int total = atomicAdd(&ctl->unsat_total, 0);
+            ctl->steps_taken = round;
+            if (set_done && total == 0) ctl->done = 1;
+            ctl->unsat_total = 0;   // re-arm for the next check
+            ctl->ticket = 0;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st) {
+    const int tiles = (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
+    hipLaunchKernelGGL(round_p1_kernel, dim3(tiles), dim3(NT), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {
+    if (a.C == 0) return hipSuccess;
+    const int bm = 16 * rb;
+    const int tiles = (a.C + bm - 1) / bm;
+    if (rb == 4) hipLaunchKernelGGL(round_p2_kernel<4>, dim3(tiles), dim3(NT), 0, st, a);
+    else if (rb == 2) hipLaunchKernelGGL(round_p2_kernel<2>, dim3(tiles), dim3(NT), 0, st, a);
+    else if (rb == 1) hipLaunchKernelGGL(round_p2_kernel<1>, dim3(tiles), dim3(NT), 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_round_p3(const RoundArgs& a, hipStream_t st) {
+    const int tiles = (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
+    hipLaunchKernelGGL(round_p3_kernel, dim3(tiles), dim3(NT), 0, st, a);
+    return hipGetLastError();
+}
+void launch_select_sat(const dsat_graph* g, const float* logits, Ctl* ctl, float* pgl, int32_t* best,
+                       float* out_logits, uint8_t* assign, int32_t* graph_unsat, int round, int set_done,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(select_sat_kernel, dim3(g->G), dim3(256), 0, st, g->var_seg, g->cl_seg, g->c_rowptr,
+                       g->c_lit, logits, ctl, pgl, best, out_logits, assign, graph_unsat, g->N, round, set_done);
+}
+
+}  // namespace dsat

@@ -150,7 +150,12 @@ class Session:
                 "solved_fraction": frac.value if want_solved_fraction else None}
 
     # -- single operators ----------------------------------------------------------------
-    def op_mlp(self, mlp: int, x: torch.Tensor) -> torch.Tensor:
+    def bench_mlp(self, mlp: int, rows: int, impl: int = 0, rb: int = 1, nwaves: int = 4, iters: int = 20) -> float:
+        us = C.c_double(0.0)
+        _lib.check(_lib.load().dsat_bench_mlp(self.handle, mlp, rows, impl, rb, nwaves, iters, C.byref(us), _stream()))
+        return us.value
+
+    def op_mlp(self, mlp: int, x: torch.Tensor, impl: int = 0, rb: int = 1, nwaves: int = 4) -> torch.Tensor:
         lib = _lib.load()
         import ctypes
         i, o = ctypes.c_int32(), ctypes.c_int32()
@@ -161,8 +166,8 @@ class Session:
         out_dim = o.value
         rows = x.shape[0]
         y = torch.empty(rows, out_dim, dtype=torch.float32, device=self.device)
-        _lib.check(lib.dsat_op_mlp(self.handle, mlp, _ptr(x, torch.float32, rows * in_dim, "x"), rows, _ptr(y),
-                                   _stream()))
+        _lib.check(lib.dsat_op_mlp_ex(self.handle, mlp, _ptr(x, torch.float32, rows * in_dim, "x"), rows, _ptr(y),
+                                      impl, rb, nwaves, _stream()))
         return y
 
     def op_clause_gather(self, q, lits):

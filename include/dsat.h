@@ -161,6 +161,15 @@ int dsat_sample(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed,
 /* MLP.call (model/mlp.py:42-50) of MLP `mlp` on x[rows, in_dim] -> y[rows, out_dim]. */
 int dsat_op_mlp(dsat_session* s, int32_t mlp, const float* x, int32_t rows, float* y,
                 void* stream);
+/* Same operator with the implementation chosen explicitly: impl 0 = one GEMM launch per Dense
+ * layer (kernels_gemm.hip), impl 1 = row-tile fused chain (kernels_chain.hip) with 16*rb rows
+ * per workgroup and `nwaves` wavefronts (rb in {1,2,4}, nwaves in {4,8}). */
+int dsat_op_mlp_ex(dsat_session* s, int32_t mlp, const float* x, int32_t rows, float* y,
+                   int32_t impl, int32_t rb, int32_t nwaves, void* stream);
+/* Measurement helper: average device time in microseconds of `iters` back-to-back runs of
+ * MLP `mlp` on `rows` rows (HIP events on `stream`; synchronises). */
+int dsat_bench_mlp(dsat_session* s, int32_t mlp, int32_t rows, int32_t impl, int32_t rb,
+                   int32_t nwaves, int32_t iters, double* avg_us, void* stream);
 /* softplus_loss_adj (loss/sat.py:125-137) fused with the literal->clause message
  * product (model/query_sat.py:255-256):
  *   closs_out[C,128] = exp(-(A^T softplus([q;-q])));  cmsg_out[C,128] = (A^T lits)*rsqrt(len)
