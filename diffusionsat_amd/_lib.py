@@ -57,6 +57,7 @@ SIGNATURES = {
     "dsat_op_is_batch_sat": (C.c_int, [_vp, _vp, C.POINTER(_i32), _vp]),
     "dsat_op_rng": (C.c_int, [_vp, _u64, _u32, _i32, _vp, _vp, _vp, _vp]),
     "dsat_session_set_profile": (C.c_int, [_vp, _i32]),
+    "dsat_session_read_stamps": (C.c_int, [_vp, C.POINTER(_i64), _i64]),
     "dsat_session_profile": (C.c_int, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                         C.POINTER(_i64)]),
 }

@@ -225,6 +225,8 @@ extern "C" int dsat_graph_create(const int32_t* clause_rowptr, const int32_t* cl
     g->N = N; g->C = C; g->G = G; g->E = E;
     g->max_clause_len = max_len; g->max_lit_deg = max_deg;
     g->h_var_seg = vseg; g->h_cl_seg = cseg;
+    g->h_c_rowptr.assign(clause_rowptr, clause_rowptr + C + 1);
+    g->h_l_rowptr = l_rowptr;
     hipError_t e = hipSuccess;
     if ((e = up(&g->c_rowptr, clause_rowptr, (size_t)C + 1)) != hipSuccess ||
         (e = up(&g->c_lit, c_lit.data(), (size_t)E)) != hipSuccess ||
@@ -422,12 +424,15 @@ struct dsat_session {
     int use_fused = 1;
     int p2_rb = 4;
     float *sp = nullptr, *psum_v = nullptr, *psum_c = nullptr;
-    int32_t *vtile_seg = nullptr, *vgseg = nullptr, *ctile_seg = nullptr, *cgseg = nullptr;
-    std::vector<int32_t> h_vtile_seg, h_vgseg, h_ctile_seg, h_cgseg;
+    int32_t *vmeta = nullptr, *vgseg = nullptr, *cmeta = nullptr, *cgseg = nullptr;
+    std::vector<int32_t> h_vtile_seg, h_vgseg, h_ctile_seg, h_cgseg, h_vmeta, h_cmeta;
+    long long* stamps = nullptr;   // [3][4096][8] when DSAT_STAMPS=1
     RoundArgs ra1, ra2, ra3;   // templates: per-launch fields (round, tail, ...) are patched in
     // graph replay
     int use_graph = 1;
     hipStream_t cap_stream = nullptr;
+    hipStream_t side_stream = nullptr;   // select/SAT of round r-1 runs beside P2/P3 of round r
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
     // profiling
     int profile = 0;
@@ -471,9 +476,9 @@ static void carve(dsat_session* s, Slab& sl) {
     s->sp = sl.take<float>(2 * N * F);
     s->psum_v = sl.take<float>(std::max<size_t>(s->h_vtile_seg.empty() ? 1 : s->h_vtile_seg.back(), 1) * F);
     s->psum_c = sl.take<float>(std::max<size_t>(s->h_ctile_seg.empty() ? 1 : s->h_ctile_seg.back(), 1) * F);
-    s->vtile_seg = sl.take<int32_t>(s->h_vtile_seg.size());
+    s->vmeta = sl.take<int32_t>(s->h_vmeta.size());
     s->vgseg = sl.take<int32_t>(s->h_vgseg.size());
-    s->ctile_seg = sl.take<int32_t>(s->h_ctile_seg.size());
+    s->cmeta = sl.take<int32_t>(s->h_cmeta.size());
     s->cgseg = sl.take<int32_t>(s->h_cgseg.size());
 }
 
@@ -495,6 +500,29 @@ static void build_segments(const std::vector<int32_t>& seg, int rows, int bm, st
     tile_seg[ntiles] = count;
     gseg.assign(G + 1, 0);
     for (int i = 0; i < G; ++i) gseg[i + 1] = gseg[i] + per_graph[i];
+}
+
+// Per-tile records (TileMetaDev in kernels_round.hip): graphs touched, first segment, the first
+// graph's row/segment ranges and the CSR entry range of the tile's rows.  `neg_off` >= 0 adds
+// the entry range of the rows shifted by neg_off (the -literal rows of a variable tile).
+static void build_tile_meta(const std::vector<int32_t>& seg, int rows, int bm, const std::vector<int32_t>& tile_seg,
+                            const std::vector<int32_t>& gseg, const int32_t* rowptr, int neg_off,
+                            std::vector<int32_t>& meta) {
+    const int G = (int)seg.size() - 1;
+    const int ntiles = (rows + bm - 1) / bm;
+    meta.assign((size_t)std::max(ntiles, 1) * TILE_META_INTS, 0);
+    int g = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int lo = t * bm, hi = std::min(rows, lo + bm);
+        while (g < G && seg[g + 1] <= lo) ++g;
+        int gl = g;
+        while (gl + 1 < G && seg[gl + 1] < hi) ++gl;
+        int32_t* m = &meta[(size_t)t * TILE_META_INTS];
+        m[0] = g; m[1] = gl; m[2] = tile_seg[t];
+        m[3] = seg[g]; m[4] = seg[g + 1]; m[5] = gseg[g]; m[6] = gseg[g + 1];
+        m[7] = rowptr[lo]; m[8] = rowptr[hi];
+        if (neg_off >= 0) { m[9] = rowptr[neg_off + lo]; m[10] = rowptr[neg_off + hi]; }
+    }
 }
 
 static ChainSpec make_chain(const std::vector<PackedLayer>& layers, int rb) {
@@ -526,7 +554,9 @@ static bool plan_round(dsat_session* s) {
     a.c_rowptr = g->c_rowptr; a.c_lit = g->c_lit; a.l_rowptr = g->l_rowptr; a.l_clause = g->l_clause;
     a.var_gid = g->var_gid; a.cl_gid = g->cl_gid; a.var_seg = g->var_seg; a.cl_seg = g->cl_seg;
     a.deg_w = g->deg_w; a.vdeg_w = g->vdeg_w; a.rev_w = g->rev_w;
-    a.vtile_seg = s->vtile_seg; a.vgseg = s->vgseg; a.ctile_seg = s->ctile_seg; a.cgseg = s->cgseg;
+    a.vmeta = s->vmeta; a.vgseg = s->vgseg; a.cmeta = s->cmeta; a.cgseg = s->cgseg;
+    a.pgl = s->pgl; a.out_logits = s->out_logits; a.best = s->best; a.graph_unsat = s->graph_unsat;
+    a.assign = s->assign;
     a.N = g->N; a.C = g->C; a.G = g->G;
     a.V = s->V; a.Cs = s->Cs; a.q = s->q; a.sp = s->sp; a.lits = s->lits; a.closs4 = s->closs4;
     a.vla = s->vla; a.ncv = s->ncv; a.newv = s->newv; a.logits = s->logits;
@@ -556,7 +586,7 @@ static bool plan_round(dsat_session* s) {
         int rb = 4;
         for (; rb >= 1; rb >>= 1) {
             const int bm = 16 * rb;
-            const int need = bm * (3 * F + 8) + bm * (hid + 8) * (layers.size() > 2 ? 2 : 1) + F;
+            const int need = bm * (3 * F + 8) + bm * (hid + 8) * (layers.size() > 2 ? 2 : 1) + 512;
             if (need <= LDS) break;
         }
         ok = ok && rb >= 1;
@@ -584,7 +614,7 @@ static bool plan_round(dsat_session* s) {
         r.off_a = ROUND_BM_VAR * r.ld_x;
         r.off_b = r.off_a + ROUND_BM_VAR * r.ld_a;
         r.off_mean = r.off_b + ROUND_BM_VAR * r.ld_b;
-        ok = ok && (r.off_mean <= LDS);
+        ok = ok && (r.off_mean + 512 <= LDS);
     }
     return ok;
 }
@@ -602,10 +632,14 @@ extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, i
         const int hid = max_hidden_pad(cl);
         int rb = 4;
         for (; rb > 1; rb >>= 1)
-            if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + F <= 40960) break;
+            if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + 512 <= 40960) break;
         s->p2_rb = rb;
         build_segments(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg);
         build_segments(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg);
+        build_tile_meta(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg, g->h_l_rowptr.data(), g->N,
+                        s->h_vmeta);
+        build_tile_meta(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg, g->h_c_rowptr.data(), -1,
+                        s->h_cmeta);
     }
     Slab dry;
     carve(s.get(), dry);
@@ -613,6 +647,9 @@ extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, i
     DSAT_HIP(hipMalloc((void**)&s->slab, s->slab_bytes));
     hipError_t e = hipMemset(s->slab, 0, s->slab_bytes);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         (void)hipFree(s->slab);
         return hip_fail(e, "session init", __FILE__, __LINE__);
@@ -624,16 +661,23 @@ extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, i
         auto cp = [](int32_t* d, const std::vector<int32_t>& h) {
             return h.empty() ? hipSuccess : hipMemcpy(d, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice);
         };
-        hipError_t e2 = cp(s->vtile_seg, s->h_vtile_seg);
+        hipError_t e2 = cp(s->vmeta, s->h_vmeta);
         if (e2 == hipSuccess) e2 = cp(s->vgseg, s->h_vgseg);
-        if (e2 == hipSuccess) e2 = cp(s->ctile_seg, s->h_ctile_seg);
+        if (e2 == hipSuccess) e2 = cp(s->cmeta, s->h_cmeta);
         if (e2 == hipSuccess) e2 = cp(s->cgseg, s->h_cgseg);
         if (e2 != hipSuccess) {
             (void)hipFree(s->slab);
             return hip_fail(e2, "segment upload", __FILE__, __LINE__);
         }
     }
+    if (const char* ev = getenv("DSAT_STAMPS")) {
+        if (atoi(ev) != 0) {
+            DSAT_HIP(hipMalloc((void**)&s->stamps, 3 * 4096 * 8 * sizeof(long long)));
+            DSAT_HIP(hipMemset(s->stamps, 0, 3 * 4096 * 8 * sizeof(long long)));
+        }
+    }
     if (!plan_round(s.get())) s->use_fused = 0;
+    if (s->stamps) { s->ra1.stamps = s->stamps; s->ra2.stamps = s->stamps + 4096 * 8; s->ra3.stamps = s->stamps + 2 * 4096 * 8; }
     if (const char* ev = getenv("DSAT_FUSED")) s->use_fused = s->use_fused && atoi(ev) != 0;
     for (int i = 0; i < KC_COUNT; ++i) { s->prof_us[i] = 0; s->prof_n[i] = 0; }
     *out = s.release();
@@ -645,8 +689,21 @@ extern "C" void dsat_session_destroy(dsat_session* s) {
     for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->cap_stream) (void)hipStreamDestroy(s->cap_stream);
+    if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->slab) (void)hipFree(s->slab);
+    if (s->stamps) (void)hipFree(s->stamps);
     delete s;
+}
+
+extern "C" int dsat_session_read_stamps(dsat_session* s, int64_t* out, int64_t n) {
+    DSAT_REQUIRE(s && out, DSAT_E_INVALID, "dsat_session_read_stamps: null argument");
+    DSAT_REQUIRE(s->stamps != nullptr, DSAT_E_STATE, "dsat_session_read_stamps: session was not created with DSAT_STAMPS=1");
+    DSAT_REQUIRE(n <= 3 * 4096 * 8, DSAT_E_INVALID, "dsat_session_read_stamps: n too large");
+    DSAT_HIP(hipDeviceSynchronize());
+    DSAT_HIP(hipMemcpy(out, s->stamps, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+    return DSAT_OK;
 }
 
 extern "C" int dsat_session_set_graph_replay(dsat_session* s, int32_t enable) {
@@ -861,14 +918,17 @@ static void enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int 
     for (int r = 0; r <= rounds; ++r) {
         a1.round = r;
         a1.tail = r == rounds;
-        L.run(KC_ROUND_P1, [&] { (void)launch_round_p1(a1, st); });
-        if (r > 0 && (early_exit || r == rounds))
+        L.run(KC_ROUND_P1, [&] { (void)launch_round_p1(a1, st); });   // also produces logits of round r-1
+        if (r == rounds) {
+            // R15-R17 of the last round (with early exit the earlier rounds' run inside P2)
             L.run(KC_SELECT_SAT, [&] {
                 launch_select_sat(s->g, s->logits, s->ctl, s->pgl, s->best, s->out_logits, s->assign,
                                   s->graph_unsat, r - 1, early_exit, st);
             });
-        if (r == rounds) break;
+            break;
+        }
         a2.round = r;
+        a2.s_enable = early_exit && r > 0;   // G extra blocks: select/SAT of round r-1
         a3.round = r;
         L.run(KC_ROUND_P2, [&] { (void)launch_round_p2(a2, s->p2_rb, st); });
         L.run(KC_ROUND_P3, [&] { (void)launch_round_p3(a3, st); });

@@ -79,6 +79,7 @@ struct dsat_graph {
     float* vdeg_w = nullptr;      // [N]   4*rsqrt(max(deg_pos+deg_neg,1)) (:195)
     float* rev_w = nullptr;       // [C]   rsqrt(max(clause_len,1))        (:197)
     std::vector<int32_t> h_var_seg, h_cl_seg;
+    std::vector<int32_t> h_c_rowptr, h_l_rowptr;   // host copies for the per-tile records
 };
 
 namespace dsat {
@@ -158,21 +159,29 @@ struct RoundArgs {
     // graph
     const int32_t *c_rowptr, *c_lit, *l_rowptr, *l_clause, *var_gid, *cl_gid, *var_seg, *cl_seg;
     const float *deg_w, *vdeg_w, *rev_w;
-    const int32_t *vtile_seg, *vgseg, *ctile_seg, *cgseg;   // PairNorm partial-sum segments
+    const int32_t *vgseg, *cgseg;     // PairNorm partial-sum segments of each graph: [gseg[g], gseg[g+1])
+    const int32_t *vmeta, *cmeta;     // per-tile records, TILE_META_INTS int32 each (see TileMetaDev)
     int N, C, G;
     // state and intermediates (HBM)
     float *V, *Cs, *q, *sp, *lits, *closs4, *vla, *ncv, *newv, *logits, *psum_v, *psum_c;
     const float* noisy;    // [N,2] noisy_num of this denoising step
     Ctl* ctl;
     float* trace_logits;   // optional [rounds,N,8]
+    // select/SAT outputs (the S blocks appended to P2 and the stand-alone S kernel)
+    float *pgl, *out_logits;
+    int32_t *best, *graph_unsat;
+    uint8_t* assign;
+    int s_enable;          // P2 only: append G blocks running select/SAT of round-1
     int round;             // message-passing round this launch belongs to
     int check_done;        // early exit armed: skip when ctl->done
     int tail;              // P1 only: run the PairNorm + output-MLP part and stop
+    long long* stamps;     // diagnostics (DSAT_STAMPS=1): [tile][8] shader-clock stamps, else nullptr
     // weights
     ChainSpec mq, mlit, mcl, mupd, mout;
     // LDS plan (float offsets / row strides), filled by plan_round_lds
     int ld_x, ld_a, ld_b, off_x, off_a, off_b, off_vlog, off_mean;
 };
+constexpr int TILE_META_INTS = 16;
 constexpr int ROUND_BM_VAR = 16;    // rows per variable-side tile
 constexpr int ROUND_NWAVES = 8;
 hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st);

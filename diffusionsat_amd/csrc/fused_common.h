@@ -187,6 +187,12 @@ __device__ __forceinline__ void dense_layer_tpw(const float* __restrict__ sIn, i
         const int t0 = base + wave * TPW;
         if (t0 >= ntiles) continue;
         f32x4 acc[RB][TPW];
+        float bv[TPW];   // requested before the k-loop: a load in the epilogue would expose its latency
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int t = t0 + j < ntiles ? t0 + j : ntiles - 1;
+            bv[j] = bias[t * 16 + (lane & 15)];
+        }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -196,12 +202,11 @@ __device__ __forceinline__ void dense_layer_tpw(const float* __restrict__ sIn, i
         for (int j = 0; j < TPW; ++j) {
             if (t0 + j < ntiles) {
                 const int col = (t0 + j) * 16 + (lane & 15);
-                const float bv = bias[col];
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float v = acc[rb][j][i] + bv;
+                        float v = acc[rb][j][i] + bv[j];
                         if (act) v = v > 0.f ? v : 0.2f * v;
                         store(rb * 16 + 4 * (lane >> 4) + i, col, v);
                     }

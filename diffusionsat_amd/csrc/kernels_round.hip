@@ -24,6 +24,12 @@ namespace dsat {
 namespace {
 
 constexpr int NT = ROUND_NWAVES * 64;
+
+// Phase stamps for the diagnostic build of a session (never read by any kernel).
+#define DSAT_STAMP(a, k)                                                                  \
+    do {                                                                                  \
+        if ((a).stamps != nullptr && threadIdx.x == 0) (a).stamps[blockIdx.x * 8 + (k)] = clock64(); \
+    } while (0)
 constexpr int LDS_FLOATS = 40960;   // 160 KiB static (see kernels_chain.hip on dynamic LDS)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -53,15 +59,48 @@ __device__ __forceinline__ void write_aux_row(float* dst, const Ctl* ctl, const 
     st4(dst + 12, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
+// Per-tile scalars precomputed on the host (one 64-B record, one load): removes the dependent
+// gid -> seg -> gseg -> rowptr chains from the kernel prologues.
+struct TileMetaDev {
+    int g_first, g_last;      // graphs with rows in this tile
+    int seg_base;             // index of this tile's first PairNorm segment
+    int s0, s1, gs0, gs1;     // rows [s0,s1) and segments [gs0,gs1) of graph g_first
+    int e_base0, e_end0;      // CSR entry range of the tile's rows (clause rows / +literal rows)
+    int e_base1, e_end1;      // CSR entry range of the tile's -literal rows (variable tiles)
+    int pad[5];
+};
+// Workgroups are dealt round-robin over the 8 XCDs (observed, speed only); this bijection gives
+// each XCD one contiguous chunk of tiles.  Graphs are contiguous row ranges on both sides of the
+// bipartite graph, so the variable tiles and the clause tiles of one formula then run on the same
+// XCD in P1, P2 and P3, and the rows one kernel gathers were written into that XCD's L2 by the
+// previous kernel (cdna_hip_programming.md T1).  Placement only affects speed.
+__device__ __forceinline__ int xcd_tile(int b, int ntiles) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+__device__ __forceinline__ TileMetaDev load_meta(const int32_t* meta, int tile) {
+    TileMetaDev m;
+    const int4* p = reinterpret_cast<const int4*>(meta + (size_t)tile * TILE_META_INTS);
+    const int4 a = p[0], b = p[1], c = p[2];
+    m.g_first = a.x; m.g_last = a.y; m.seg_base = a.z; m.s0 = a.w;
+    m.s1 = b.x; m.gs0 = b.y; m.gs1 = b.z; m.e_base0 = b.w;
+    m.e_end0 = c.x; m.e_base1 = c.y; m.e_end1 = c.z;
+    return m;
+}
+
 // state = 0.25*PairNorm(x) + 0.1*state for the rows of one tile (layers/normalization.py:43-71,
 // query_sat.py:265-266 / :279-280), then the :347-348 mix for the copy that enters the next
 // round.  sState[.][0..127] receives the carried state, sLogit (optional) the pre-mix value.
+// Row r of the tile belongs to half-wave (r mod 16); its x / state rows are requested before
+// the per-graph mean is known, so the kernel pays one memory latency, not one per level.
 template <int BM>
-__device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const int32_t* __restrict__ gid,
+__device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileMetaDev& tm,
                                               const int32_t* __restrict__ seg, const int32_t* __restrict__ gseg,
                                               const float* __restrict__ psum, const float* __restrict__ x,
                                               float* __restrict__ state, bool first, float* sState, int ldS,
                                               float* sLogit, int ldL, float* sMean, int tid) {
+    constexpr int ROWS = BM / (NT / 32);
     const int tile_hi = min(tile_lo + BM, rows);
     const int sub = tid & 31, hw = tid >> 5;
     // padding rows of the last tile: finite zeros for the MFMAs
@@ -75,61 +114,88 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const int32
             st4(sState + (r - tile_lo) * ldS + sub * 4, one);
             st4(state + (size_t)r * F + sub * 4, one);
         }
+        __syncthreads();
         return;
     }
-    const int g_first = gid[tile_lo], g_last = gid[tile_hi - 1];
-    for (int g = g_first; g <= g_last; ++g) {
-        const int s0 = seg[g], s1 = seg[g + 1];
+    float4 xv[ROWS], ov[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const int r = tile_lo + hw + k * (NT / 32);
+        if (r < tile_hi) {
+            xv[k] = ld4(x + (size_t)r * F + sub * 4);
+            ov[k] = ld4(state + (size_t)r * F + sub * 4);
+        }
+    }
+    for (int g = tm.g_first; g <= tm.g_last; ++g) {
+        int s0, s1, gs0, gs1;
+        if (g == tm.g_first) { s0 = tm.s0; s1 = tm.s1; gs0 = tm.gs0; gs1 = tm.gs1; }
+        else { s0 = seg[g]; s1 = seg[g + 1]; gs0 = gseg[g]; gs1 = gseg[g + 1]; }
         const int lo = max(s0, tile_lo), hi = min(s1, tile_hi);
         if (lo >= hi) continue;   // wave-uniform
         if (tid < F) {
             float m = 0.f;
-            for (int s = gseg[g]; s < gseg[g + 1]; ++s) m += psum[(size_t)s * F + tid];
+            for (int sgi = gs0; sgi < gs1; ++sgi) m += psum[(size_t)sgi * F + tid];
             sMean[tid] = m * (1.f / (float)(s1 - s0));
         }
         __syncthreads();
         const float4 mean = ld4(sMean + sub * 4);
-        for (int r = lo + hw; r < hi; r += NT / 32) {
-            float4 v = ld4(x + (size_t)r * F + sub * 4);
-            v.x -= mean.x; v.y -= mean.y; v.z -= mean.z; v.w -= mean.w;
-            float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-            const float rs = 1.f / sqrtf(ss * (1.f / F) + 1e-6f);
-            const float4 o4 = ld4(state + (size_t)r * F + sub * 4);
-            float4 res;
-            res.x = v.x * rs * 0.25f + 0.1f * o4.x; res.y = v.y * rs * 0.25f + 0.1f * o4.y;
-            res.z = v.z * rs * 0.25f + 0.1f * o4.z; res.w = v.w * rs * 0.25f + 0.1f * o4.w;
-            if (sLogit != nullptr) st4(sLogit + (r - tile_lo) * ldL + sub * 4, res);
-            res.x = __fadd_rn(__fmul_rn(res.x, 0.2f), __fmul_rn(res.x, 0.8f));
-            res.y = __fadd_rn(__fmul_rn(res.y, 0.2f), __fmul_rn(res.y, 0.8f));
-            res.z = __fadd_rn(__fmul_rn(res.z, 0.2f), __fmul_rn(res.z, 0.8f));
-            res.w = __fadd_rn(__fmul_rn(res.w, 0.2f), __fmul_rn(res.w, 0.8f));
-            st4(sState + (r - tile_lo) * ldS + sub * 4, res);
-            st4(state + (size_t)r * F + sub * 4, res);
+        for (int k = 0; k < ROWS; ++k) {
+            const int r = tile_lo + hw + k * (NT / 32);
+            if (r >= lo && r < hi) {
+                float4 v = xv[k];
+                v.x -= mean.x; v.y -= mean.y; v.z -= mean.z; v.w -= mean.w;
+                float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+                const float rs = 1.f / sqrtf(ss * (1.f / F) + 1e-6f);
+                const float4 o4 = ov[k];
+                float4 res;
+                res.x = v.x * rs * 0.25f + 0.1f * o4.x; res.y = v.y * rs * 0.25f + 0.1f * o4.y;
+                res.z = v.z * rs * 0.25f + 0.1f * o4.z; res.w = v.w * rs * 0.25f + 0.1f * o4.w;
+                if (sLogit != nullptr) st4(sLogit + (r - tile_lo) * ldL + sub * 4, res);
+                res.x = __fadd_rn(__fmul_rn(res.x, 0.2f), __fmul_rn(res.x, 0.8f));
+                res.y = __fadd_rn(__fmul_rn(res.y, 0.2f), __fmul_rn(res.y, 0.8f));
+                res.z = __fadd_rn(__fmul_rn(res.z, 0.2f), __fmul_rn(res.z, 0.8f));
+                res.w = __fadd_rn(__fmul_rn(res.w, 0.2f), __fmul_rn(res.w, 0.8f));
+                st4(sState + (r - tile_lo) * ldS + sub * 4, res);
+                st4(state + (size_t)r * F + sub * 4, res);
+            }
         }
         __syncthreads();
     }
 }
 
 // Column sums of the tile's new rows (staged in LDS, ld = ldT), one segment per graph touched.
+// Four thread groups each add a quarter of the segment's rows; the quarters are combined in
+// a fixed order.  sPart: NT floats of LDS.
 template <int BM>
-__device__ __forceinline__ void tile_colsums(int tile_lo, int rows, const int32_t* __restrict__ gid,
-                                             const int32_t* __restrict__ seg, int seg_base,
-                                             float* __restrict__ psum, const float* sT, int ldT, int tid) {
+__device__ __forceinline__ void tile_colsums(int tile_lo, int rows, const TileMetaDev& tm,
+                                             const int32_t* __restrict__ seg, float* __restrict__ psum,
+                                             const float* sT, int ldT, float* sPart, int tid) {
     const int tile_hi = min(tile_lo + BM, rows);
     if (tile_hi <= tile_lo) return;
-    const int g_first = gid[tile_lo], g_last = gid[tile_hi - 1];
-    const int c = tid & (F - 1), lane_grp = tid / F, ngrp = NT / F;
+    const int c = tid & (F - 1), grp = tid / F;
+    constexpr int NG = NT / F;
     int ord = 0;
-    for (int g = g_first; g <= g_last; ++g) {
-        const int lo = max(seg[g], tile_lo), hi = min(seg[g + 1], tile_hi);
+    for (int g = tm.g_first; g <= tm.g_last; ++g) {
+        int s0, s1;
+        if (g == tm.g_first) { s0 = tm.s0; s1 = tm.s1; } else { s0 = seg[g]; s1 = seg[g + 1]; }
+        const int lo = max(s0, tile_lo), hi = min(s1, tile_hi);
         if (lo >= hi) continue;
-        if (ord % ngrp == lane_grp) {
-            float s = 0.f;
-            for (int r = lo; r < hi; ++r) s += sT[(r - tile_lo) * ldT + c];
-            psum[(size_t)(seg_base + ord) * F + c] = s;
+        const int len = hi - lo, per = (len + NG - 1) / NG;
+        const int a0 = lo + grp * per, a1 = min(a0 + per, hi);
+        float sacc = 0.f;
+        for (int r = a0; r < a1; ++r) sacc += sT[(r - tile_lo) * ldT + c];
+        sPart[tid] = sacc;
+        __syncthreads();
+        if (tid < F) {
+            float t = sPart[tid];
+#pragma unroll
+            for (int k = 1; k < NG; ++k) t += sPart[k * F + tid];
+            psum[(size_t)(tm.seg_base + ord) * F + tid] = t;
         }
+        __syncthreads();
         ++ord;
     }
 }
@@ -158,14 +224,36 @@ __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, 
     }
 }
 
+// CSR entries of the tile's rows -> LDS (entry ranges of consecutive rows are contiguous):
+// sPtr[i] = rowptr[row_lo + i] - e_base for i = 0..nrows, sIdx[k] = idx[e_base + k].
+// Returns false (nothing staged) when the range does not fit `cap` entries.
+__device__ __forceinline__ bool stage_csr(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
+                                          int row_lo, int nrows, int e_base, int e_end, int* sPtr, int* sIdx,
+                                          int cap, int tid) {
+    if (e_end - e_base > cap) return false;
+    if (tid <= nrows) sPtr[tid] = rowptr[row_lo + tid] - e_base;
+    for (int k = tid; k < e_end - e_base; k += NT) sIdx[k] = idx[e_base + k];
+    return true;
+}
+
+// R15-R17 for one graph (forward declaration; defined with the stand-alone kernel below)
+template <int NTH>
+__device__ void select_sat_body(int g, int ngraphs, const int32_t* __restrict__ vseg,
+                                const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
+                                const int32_t* __restrict__ c_lit, const float* __restrict__ logits,
+                                Ctl* __restrict__ ctl, float* __restrict__ pgl, int32_t* __restrict__ best,
+                                float* __restrict__ out_logits, uint8_t* __restrict__ assign,
+                                int32_t* __restrict__ graph_unsat, int N, int round, int set_done, float* sred);
+
 // ------------------------------------------------------------------------------------- P1
 __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     if (a.check_done && a.ctl->done != 0) return;
     constexpr int BM = ROUND_BM_VAR;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tile_lo = blockIdx.x * BM;
     const int N = a.N;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int tile_lo = tile * BM;
     float* sX = smem + a.off_x;
     float* sVlog = smem + a.off_vlog;
     float* sA = smem + a.off_a;
@@ -173,13 +261,15 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     float* sMean = smem + a.off_mean;
     const int ldx = a.ld_x, ldv = F + 8;
 
-    pairnorm_tile<BM>(tile_lo, N, a.var_gid, a.var_seg, a.vgseg, a.psum_v, a.newv, a.V, a.round == 0, sX, ldx,
-                      sVlog, ldv, sMean, tid);
-    if (tid < BM) {   // aux columns of v1 for this round
+    DSAT_STAMP(a, 0);
+    const TileMetaDev tm = load_meta(a.vmeta, tile);
+    if (tid < BM) {   // aux columns of v1 for this round (independent of everything else)
         const int n = tile_lo + tid;
         write_aux_row(sX + tid * ldx + F, a.ctl, a.noisy, n, N, a.round, n < N && !a.tail);
     }
-    __syncthreads();
+    pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.newv, a.V, a.round == 0, sX, ldx, sVlog,
+                      ldv, sMean, tid);
+    DSAT_STAMP(a, 1);
 
     if (a.round > 0) {   // R14: logits of the previous round from the pre-mix state
         float* lg = a.logits;
@@ -192,6 +282,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
             }
         });
     }
+    DSAT_STAMP(a, 2);
     if (a.tail) return;
 
     {   // R2: query = variables_query(v1); softplus(+-query) feeds the clause gather (loss/sat.py:132-133)
@@ -206,6 +297,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
             }
         });
     }
+    DSAT_STAMP(a, 3);
     {   // R6: literals = [lit_mlp(v1)[:, :128] ; [:, 128:]]
         float* lits = a.lits;
         run_chain<1>(a.mlit, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float v) {
@@ -213,64 +305,113 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
             if (n < N && col < 2 * F) lits[((size_t)(col < F ? n : N + n)) * F + (col & (F - 1))] = v;
         });
     }
+    DSAT_STAMP(a, 4);
 }
 
 // ------------------------------------------------------------------------------------- P2
+// Blocks [0, tiles) are clause tiles; blocks [tiles, tiles+G) (when s_enable) run the
+// select/SAT step of the PREVIOUS round for one graph each, on CUs the tiles leave idle:
+// it only feeds the early-exit flag and the step outputs, so it needs no launch of its own.
 template <int RB>
 __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     if (a.check_done && a.ctl->done != 0) return;
     constexpr int BM = 16 * RB;
+    constexpr int ROWS = BM / (NT / 32);   // clause rows per half-wave
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tile_lo = blockIdx.x * BM;
     const int C = a.C, N = a.N;
+    const int tiles = (C + BM - 1) / BM;
+    if ((int)blockIdx.x >= tiles) {
+        select_sat_body<NT>(blockIdx.x - tiles, a.G, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
+                            a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, N, a.round - 1, a.check_done,
+                            smem);
+        return;
+    }
+    const int tile = xcd_tile(blockIdx.x, tiles);
+    const int tile_lo = tile * BM;
+    const int tile_hi = min(tile_lo + BM, C);
     float* sX = smem + a.off_x;
     float* sA = smem + a.off_a;
     float* sB = smem + a.off_b;
     float* sMean = smem + a.off_mean;
     const int ldx = a.ld_x;
 
-    pairnorm_tile<BM>(tile_lo, C, a.cl_gid, a.cl_seg, a.cgseg, a.psum_c, a.ncv, a.Cs, a.round == 0, sX, ldx,
-                      nullptr, 0, sMean, tid);
-    // R3 + R5 + R7: one half-wave per clause row walks the clause's literals
+    DSAT_STAMP(a, 0);
+    const TileMetaDev tm = load_meta(a.cmeta, tile);
+    // the clause rows' literal lists -> LDS (sA is free until the first layer writes it)
+    int* sPtr = reinterpret_cast<int*>(sA);
+    int* sIdx = sPtr + BM + 8;
+    const bool staged = stage_csr(a.c_rowptr, a.c_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr,
+                                  sIdx, BM * a.ld_a - (BM + 8), tid);
+    pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c, a.ncv, a.Cs, a.round == 0, sX, ldx, nullptr, 0,
+                      sMean, tid);   // its barriers also publish sPtr / sIdx
+    DSAT_STAMP(a, 1);
+    // R3 + R5 + R7: half-wave hw owns rows hw, hw+16, ...; two rows are in flight at a time
     {
         const int sub = tid & 31, hw = tid >> 5;
-        for (int r = hw; r < BM; r += NT / 32) {
-            const int c = tile_lo + r;
-            float4 S = make_float4(0.f, 0.f, 0.f, 0.f), M = S;
-            float rw = 0.f;
-            if (c < C) {
-                const int e0 = a.c_rowptr[c], e1 = a.c_rowptr[c + 1];
-                rw = a.rev_w[c];
-                for (int e = e0; e < e1; e += 4) {
-                    int l[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) l[j] = (e + j < e1) ? a.c_lit[e + j] : -1;
-                    float4 sv[4], lv[4];
+        for (int kp = 0; kp < ROWS; kp += 2) {
+            float4 S[2], M[2];
+            int e0[2], e1[2];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (l[j] >= 0) {
-                            sv[j] = ld4(a.sp + (size_t)l[j] * F + sub * 4);
-                            lv[j] = ld4(a.lits + (size_t)l[j] * F + sub * 4);
-                        }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (l[j] >= 0) {
-                            S.x += sv[j].x; S.y += sv[j].y; S.z += sv[j].z; S.w += sv[j].w;
-                            M.x += lv[j].x; M.y += lv[j].y; M.z += lv[j].z; M.w += lv[j].w;
-                        }
+            for (int u = 0; u < 2; ++u) {
+                S[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                M[u] = S[u];
+                const int r = hw + (kp + u) * (NT / 32);
+                e0[u] = 0; e1[u] = 0;
+                if (kp + u < ROWS && tile_lo + r < tile_hi) {
+                    if (staged) { e0[u] = sPtr[r]; e1[u] = sPtr[r + 1]; }
+                    else { e0[u] = a.c_rowptr[tile_lo + r]; e1[u] = a.c_rowptr[tile_lo + r + 1]; }
                 }
             }
-            float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < C) {
-                cl = make_float4(4.f * expf(-S.x), 4.f * expf(-S.y), 4.f * expf(-S.z), 4.f * expf(-S.w));
-                st4(a.closs4 + (size_t)c * F + sub * 4, cl);
+            const int nmax = max(e1[0] - e0[0], e1[1] - e0[1]);
+            for (int off = 0; off < nmax; off += 4) {
+                int l[2][4];
+                float4 sv[2][4], lv[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = e0[u] + off + j;
+                        l[u][j] = e < e1[u] ? (staged ? sIdx[e] : a.c_lit[e]) : -1;
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (l[u][j] >= 0) {
+                            sv[u][j] = ld4(a.sp + (size_t)l[u][j] * F + sub * 4);
+                            lv[u][j] = ld4(a.lits + (size_t)l[u][j] * F + sub * 4);
+                        }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (l[u][j] >= 0) {
+                            S[u].x += sv[u][j].x; S[u].y += sv[u][j].y; S[u].z += sv[u][j].z; S[u].w += sv[u][j].w;
+                            M[u].x += lv[u][j].x; M[u].y += lv[u][j].y; M[u].z += lv[u][j].z; M[u].w += lv[u][j].w;
+                        }
             }
-            st4(sX + r * ldx + F + sub * 4, make_float4(M.x * rw, M.y * rw, M.z * rw, M.w * rw));
-            st4(sX + r * ldx + 2 * F + sub * 4, cl);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (kp + u >= ROWS) continue;
+                const int r = hw + (kp + u) * (NT / 32);
+                const int c = tile_lo + r;
+                float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
+                float rw = 0.f;
+                if (c < C) {
+                    rw = a.rev_w[c];
+                    cl = make_float4(4.f * expf(-S[u].x), 4.f * expf(-S[u].y), 4.f * expf(-S[u].z),
+                                     4.f * expf(-S[u].w));
+                    st4(a.closs4 + (size_t)c * F + sub * 4, cl);
+                }
+                st4(sX + r * ldx + F + sub * 4, make_float4(M[u].x * rw, M[u].y * rw, M[u].z * rw, M[u].w * rw));
+                st4(sX + r * ldx + 2 * F + sub * 4, cl);
+            }
         }
     }
     __syncthreads();
+    DSAT_STAMP(a, 2);
     {   // R8-R9: clause_data = clause_mlp([clause_state, clause_messages, clauses_loss])
         float* vla = a.vla;
         float* ncv = a.ncv;
@@ -285,9 +426,10 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
                 if (c < C) ncv[(size_t)c * F + (col - F)] = v;
             }
         });
-        tile_colsums<BM>(tile_lo, C, a.cl_gid, a.cl_seg, a.ctile_seg[blockIdx.x], a.psum_c, stage, lds, tid);
+        DSAT_STAMP(a, 3);
+        tile_colsums<BM>(tile_lo, C, tm, a.cl_seg, a.psum_c, stage, lds, sMean, tid);
+        DSAT_STAMP(a, 4);
     }
-    (void)N;
 }
 
 // ------------------------------------------------------------------------------------- P3
@@ -295,72 +437,126 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     if (a.check_done && a.ctl->done != 0) return;
     constexpr int BM = ROUND_BM_VAR;
+    constexpr int PASSES = BM / ROUND_NWAVES;   // variables per wave
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tile_lo = blockIdx.x * BM;
     const int N = a.N;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int tile_lo = tile * BM;
+    const int tile_hi = min(tile_lo + BM, N);
     float* sX = smem + a.off_x;
     float* sA = smem + a.off_a;
     float* sB = smem + a.off_b;
+    float* sPart = smem + a.off_mean;
     const int ldx = a.ld_x;
     // unit = [variables_grad | variables | aux | loss_pos | loss_neg]        (query_sat.py:277)
     constexpr int OFF_V = F, OFF_AUX = 2 * F, OFF_POS = 2 * F + AUX_W, OFF_NEG = 3 * F + AUX_W;
+    DSAT_STAMP(a, 0);
+    const TileMetaDev tm = load_meta(a.vmeta, tile);
     {   // R4 + R11: one wave per variable, half 0 = literal +v, half 1 = literal -v
         const int sub = lane & 31, half = lane >> 5;
-        for (int r = wave; r < BM; r += ROUND_NWAVES) {
-            const int v = tile_lo + r;
-            float4 M = make_float4(0.f, 0.f, 0.f, 0.f), VL = M;
-            float dw = 0.f;
+        // literal -> clause lists of the tile's +v rows and -v rows -> LDS (sA is free until layer 0)
+        int* sPtr0 = reinterpret_cast<int*>(sA);
+        int* sPtr1 = sPtr0 + BM + 8;
+        int* sIdx0 = sPtr1 + BM + 8;
+        const int cap = (BM * a.ld_a - 2 * (BM + 8)) / 2;
+        int* sIdx1 = sIdx0 + cap;
+        const int nrows = tile_hi - tile_lo;
+        const bool st0 = stage_csr(a.l_rowptr, a.l_clause, tile_lo, nrows, tm.e_base0, tm.e_end0, sPtr0, sIdx0, cap, tid);
+        const bool st1 = stage_csr(a.l_rowptr, a.l_clause, N + tile_lo, nrows, tm.e_base1, tm.e_end1, sPtr1, sIdx1, cap, tid);
+        const bool staged = st0 && st1;
+        // rows that do not depend on the lists: q (half 0) and the carried state (half 1)
+        float4 rowv[PASSES];
+        float wdeg[PASSES], wv[PASSES];
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            const int v = tile_lo + wave + u * ROUND_NWAVES;
+            rowv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            wdeg[u] = 0.f; wv[u] = 0.f;
             if (v < N) {
-                const int lit = v + half * N;
-                const int e0 = a.l_rowptr[lit], e1 = a.l_rowptr[lit + 1];
-                dw = a.deg_w[lit];
-                for (int e = e0; e < e1; e += 4) {
-                    int ci[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ci[j] = (e + j < e1) ? a.l_clause[e + j] : -1;
-                    float4 cv[4], vv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (ci[j] >= 0) {
-                            cv[j] = ld4(a.closs4 + (size_t)ci[j] * F + sub * 4);
-                            vv[j] = ld4(a.vla + (size_t)ci[j] * F + sub * 4);
-                        }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (ci[j] >= 0) {
-                            M.x += cv[j].x; M.y += cv[j].y; M.z += cv[j].z; M.w += cv[j].w;
-                            VL.x += vv[j].x; VL.y += vv[j].y; VL.z += vv[j].z; VL.w += vv[j].w;
-                        }
-                }
-            }
-            st4(sX + r * ldx + (half ? OFF_NEG : OFF_POS) + sub * 4,
-                make_float4(VL.x * dw, VL.y * dw, VL.z * dw, VL.w * dw));
-            float4 Mo;
-            Mo.x = __shfl_xor(M.x, 32); Mo.y = __shfl_xor(M.y, 32);
-            Mo.z = __shfl_xor(M.z, 32); Mo.w = __shfl_xor(M.w, 32);
-            if (half == 0) {   // closed form of the inner tape; closs4 = 4*closs, 0.25 is exact
-                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (v < N) {
-                    const float4 qv = ld4(a.q + (size_t)v * F + sub * 4);
-                    const float vw = a.vdeg_w[v];
-                    g.x = (-sigmoid_f(qv.x) * (M.x * 0.25f) + sigmoid_f(-qv.x) * (Mo.x * 0.25f)) * vw;
-                    g.y = (-sigmoid_f(qv.y) * (M.y * 0.25f) + sigmoid_f(-qv.y) * (Mo.y * 0.25f)) * vw;
-                    g.z = (-sigmoid_f(qv.z) * (M.z * 0.25f) + sigmoid_f(-qv.z) * (Mo.z * 0.25f)) * vw;
-                    g.w = (-sigmoid_f(qv.w) * (M.w * 0.25f) + sigmoid_f(-qv.w) * (Mo.w * 0.25f)) * vw;
-                }
-                st4(sX + r * ldx + sub * 4, g);
-            } else {
-                float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (v < N) vv = ld4(a.V + (size_t)v * F + sub * 4);
-                st4(sX + r * ldx + OFF_V + sub * 4, vv);
+                rowv[u] = half == 0 ? ld4(a.q + (size_t)v * F + sub * 4) : ld4(a.V + (size_t)v * F + sub * 4);
+                wdeg[u] = a.deg_w[v + half * N];
+                wv[u] = a.vdeg_w[v];
             }
         }
         if (tid < BM) {
             const int n = tile_lo + tid;
             write_aux_row(sX + tid * ldx + OFF_AUX, a.ctl, a.noisy, n, N, a.round, n < N);
         }
+        __syncthreads();   // lists staged
+        float4 M[PASSES], VL[PASSES];
+        int e0[PASSES], e1[PASSES];
+        int nmax = 0;
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            M[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            VL[u] = M[u];
+            const int r = wave + u * ROUND_NWAVES;
+            e0[u] = 0; e1[u] = 0;
+            if (tile_lo + r < N) {
+                if (staged) {
+                    const int* sp_ = half ? sPtr1 : sPtr0;
+                    e0[u] = sp_[r]; e1[u] = sp_[r + 1];
+                } else {
+                    const int lit = tile_lo + r + half * N;
+                    e0[u] = a.l_rowptr[lit]; e1[u] = a.l_rowptr[lit + 1];
+                }
+            }
+            nmax = max(nmax, e1[u] - e0[u]);
+        }
+        nmax = max(nmax, __shfl_xor(nmax, 32));   // both halves run the same trip count
+        const int* sIdx = half ? sIdx1 : sIdx0;
+        for (int off = 0; off < nmax; off += 4) {
+            int ci[PASSES][4];
+            float4 cv[PASSES][4], vv[PASSES][4];
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e0[u] + off + j;
+                    ci[u][j] = e < e1[u] ? (staged ? sIdx[e] : a.l_clause[e]) : -1;
+                }
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ci[u][j] >= 0) {
+                        cv[u][j] = ld4(a.closs4 + (size_t)ci[u][j] * F + sub * 4);
+                        vv[u][j] = ld4(a.vla + (size_t)ci[u][j] * F + sub * 4);
+                    }
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ci[u][j] >= 0) {
+                        M[u].x += cv[u][j].x; M[u].y += cv[u][j].y; M[u].z += cv[u][j].z; M[u].w += cv[u][j].w;
+                        VL[u].x += vv[u][j].x; VL[u].y += vv[u][j].y; VL[u].z += vv[u][j].z; VL[u].w += vv[u][j].w;
+                    }
+        }
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            const int r = wave + u * ROUND_NWAVES;
+            const float dw = wdeg[u];
+            st4(sX + r * ldx + (half ? OFF_NEG : OFF_POS) + sub * 4,
+                make_float4(VL[u].x * dw, VL[u].y * dw, VL[u].z * dw, VL[u].w * dw));
+            float4 Mo;
+            Mo.x = __shfl_xor(M[u].x, 32); Mo.y = __shfl_xor(M[u].y, 32);
+            Mo.z = __shfl_xor(M[u].z, 32); Mo.w = __shfl_xor(M[u].w, 32);
+            if (half == 0) {   // closed form of the inner tape; closs4 = 4*closs, 0.25 is exact
+                const float4 qv = rowv[u];
+                const float vw = wv[u];
+                float4 g;
+                g.x = (-sigmoid_f(qv.x) * (M[u].x * 0.25f) + sigmoid_f(-qv.x) * (Mo.x * 0.25f)) * vw;
+                g.y = (-sigmoid_f(qv.y) * (M[u].y * 0.25f) + sigmoid_f(-qv.y) * (Mo.y * 0.25f)) * vw;
+                g.z = (-sigmoid_f(qv.z) * (M[u].z * 0.25f) + sigmoid_f(-qv.z) * (Mo.z * 0.25f)) * vw;
+                g.w = (-sigmoid_f(qv.w) * (M[u].w * 0.25f) + sigmoid_f(-qv.w) * (Mo.w * 0.25f)) * vw;
+                st4(sX + r * ldx + sub * 4, g);
+            } else {
+                st4(sX + r * ldx + OFF_V + sub * 4, rowv[u]);
+            }
+        }
     }
     __syncthreads();
+    DSAT_STAMP(a, 1);
     {   // R12: new_variables = update_gate(unit)
         float* newv = a.newv;
         float* stage = sX;
@@ -372,7 +568,9 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
                 if (n < N) newv[(size_t)n * F + col] = v;
             }
         });
-        tile_colsums<BM>(tile_lo, N, a.var_gid, a.var_seg, a.vtile_seg[blockIdx.x], a.psum_v, stage, lds, tid);
+        DSAT_STAMP(a, 2);
+        tile_colsums<BM>(tile_lo, N, tm, a.var_seg, a.psum_v, stage, lds, sPart, tid);
+        DSAT_STAMP(a, 3);
     }
 }
 
@@ -385,15 +583,18 @@ __device__ __forceinline__ float bern_kl(float a, float b) {
     return a * (logf(a) - logf(b)) + (1.f - a) * (log1pf(-a) - log1pf(-b));
 }
 
-__global__ __launch_bounds__(256) void select_sat_kernel(
-    const int32_t* __restrict__ vseg, const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ c_lit, const float* __restrict__ logits, Ctl* __restrict__ ctl,
-    float* __restrict__ pgl, int32_t* __restrict__ best, float* __restrict__ out_logits,
-    uint8_t* __restrict__ assign, int32_t* __restrict__ graph_unsat, int N, int round, int set_done) {
-    if (set_done && ctl->done != 0) return;
-    __shared__ float red[256][LOGIT_MAPS + 1];
-    __shared__ int s_best, s_unsat;
-    const int g = blockIdx.x;
+template <int NTH>
+__device__ void select_sat_body(int g, int ngraphs, const int32_t* __restrict__ vseg,
+                                const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
+                                const int32_t* __restrict__ c_lit, const float* __restrict__ logits,
+                                Ctl* __restrict__ ctl, float* __restrict__ pgl, int32_t* __restrict__ best,
+                                float* __restrict__ out_logits, uint8_t* __restrict__ assign,
+                                int32_t* __restrict__ graph_unsat, int N, int round, int set_done, float* sred) {
+    // sred: NTH*(LOGIT_MAPS+1) + 2 floats of LDS
+    float (*red)[LOGIT_MAPS + 1] = reinterpret_cast<float (*)[LOGIT_MAPS + 1]>(sred);
+    int* s_best = reinterpret_cast<int*>(sred + NTH * (LOGIT_MAPS + 1));
+    int* s_unsat = s_best + 1;
+    const int tid = threadIdx.x;
     const int v0 = vseg[g], v1 = vseg[g + 1];
     const float t = powf(ctl->noise_scale, 0.5f);
     const float tl = fminf(t + 0.01f, 1.f);
@@ -401,7 +602,7 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
     float acc[LOGIT_MAPS];
 #pragma unroll
     for (int k = 0; k < LOGIT_MAPS; ++k) acc[k] = 0.f;
-    for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+    for (int v = v0 + tid; v < v1; v += NTH) {
         int label;
         if (ctl->inj_labels != nullptr) {
             label = ctl->inj_labels[ctl->labels_step_stride * ctl->step + v];
@@ -420,17 +621,17 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
         }
     }
 #pragma unroll
-    for (int k = 0; k < LOGIT_MAPS; ++k) red[threadIdx.x][k] = acc[k];
-    if (threadIdx.x == 0) s_unsat = 0;
+    for (int k = 0; k < LOGIT_MAPS; ++k) red[tid][k] = acc[k];
+    if (tid == 0) *s_unsat = 0;
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) {
+    for (int s = NTH / 2; s >= 1; s >>= 1) {
+        if (tid < s) {
 #pragma unroll
-            for (int k = 0; k < LOGIT_MAPS; ++k) red[threadIdx.x][k] += red[threadIdx.x + s][k];
+            for (int k = 0; k < LOGIT_MAPS; ++k) red[tid][k] += red[tid + s][k];
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         const float inv = 1.f / (float)(v1 - v0);
         int bi = 0;
         float bv = red[0][0] * inv;
@@ -441,18 +642,18 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
             if (x < bv) { bv = x; bi = k; }   // first minimum wins, as TF's CPU ArgMin
         }
         best[g] = bi;
-        s_best = bi;
+        *s_best = bi;
     }
     __syncthreads();
-    const int bi = s_best;
-    for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+    const int bi = *s_best;
+    for (int v = v0 + tid; v < v1; v += NTH) {
         const float x = logits[(size_t)v * LOGIT_MAPS + bi];
         out_logits[v] = x;
         assign[v] = (uint8_t)rintf(sigmoid_f(x));   // tf.round(tf.sigmoid(.)), half-to-even
     }
     __syncthreads();   // this workgroup's assign[] stores are visible to its own loads (same CU L1)
     int unsat = 0;
-    for (int c = cseg[g] + threadIdx.x; c < cseg[g + 1]; c += 256) {
+    for (int c = cseg[g] + tid; c < cseg[g + 1]; c += NTH) {
         bool sat = false;
         for (int e = rowptr[c]; e < rowptr[c + 1]; ++e) {
             const int l = c_lit[e];
@@ -460,14 +661,14 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
         }
         unsat += sat ? 0 : 1;
     }
-    if (unsat) atomicAdd(&s_unsat, unsat);
+    if (unsat) atomicAdd(s_unsat, unsat);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        graph_unsat[g] = s_unsat;
-        if (s_unsat) atomicAdd(&ctl->unsat_total, s_unsat);
+    if (tid == 0) {
+        graph_unsat[g] = *s_unsat;
+        if (*s_unsat) atomicAdd(&ctl->unsat_total, *s_unsat);
         __threadfence();
         const int tk = atomicAdd(&ctl->ticket, 1);
-        if (tk == (int)gridDim.x - 1) {
+        if (tk == ngraphs - 1) {
             const int total = atomicAdd(&ctl->unsat_total, 0);
             ctl->steps_taken = round;
             if (set_done && total == 0) ctl->done = 1;
@@ -475,6 +676,17 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
             ctl->ticket = 0;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void select_sat_kernel(
+    const int32_t* __restrict__ vseg, const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ c_lit, const float* __restrict__ logits, Ctl* __restrict__ ctl,
+    float* __restrict__ pgl, int32_t* __restrict__ best, float* __restrict__ out_logits,
+    uint8_t* __restrict__ assign, int32_t* __restrict__ graph_unsat, int N, int round, int set_done) {
+    if (set_done && ctl->done != 0) return;
+    __shared__ float sred[256 * (LOGIT_MAPS + 1) + 2];
+    select_sat_body<256>(blockIdx.x, gridDim.x, vseg, cseg, rowptr, c_lit, logits, ctl, pgl, best, out_logits,
+                         assign, graph_unsat, N, round, set_done, sred);
 }
 
 }  // namespace
@@ -485,9 +697,9 @@ hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {
-    if (a.C == 0) return hipSuccess;
     const int bm = 16 * rb;
-    const int tiles = (a.C + bm - 1) / bm;
+    const int tiles = (a.C + bm - 1) / bm + (a.s_enable ? a.G : 0);
+    if (tiles == 0) return hipSuccess;
     if (rb == 4) hipLaunchKernelGGL(round_p2_kernel<4>, dim3(tiles), dim3(NT), 0, st, a);
     else if (rb == 2) hipLaunchKernelGGL(round_p2_kernel<2>, dim3(tiles), dim3(NT), 0, st, a);
     else if (rb == 1) hipLaunchKernelGGL(round_p2_kernel<1>, dim3(tiles), dim3(NT), 0, st, a);

@@ -198,6 +198,10 @@ int dsat_op_rng(dsat_session* s, uint64_t seed, uint32_t step_index, int32_t rou
  * dsat_session_set_profile(s, 1) (HIP events on the launch stream, eager mode).
  * names/us_out have room for `cap` entries; returns the number of kernel classes. */
 int dsat_session_set_profile(dsat_session* s, int32_t enable);
+/* Diagnostics: when the session was created with the environment variable DSAT_STAMPS=1 the
+ * fused round kernels record shader-clock stamps at their phase boundaries; this copies
+ * the last launch's stamps ([3 kernels][4096 tiles][8 phases] int64) to host `out`. */
+int dsat_session_read_stamps(dsat_session* s, int64_t* out, int64_t n);
 int dsat_session_profile(dsat_session* s, int32_t cap, const char** names, double* us_out,
                          int64_t* launches_out);
 
