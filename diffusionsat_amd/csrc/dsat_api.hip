@@ -475,7 +475,7 @@ static void carve(dsat_session* s, Slab& sl) {
     s->ctl = sl.take<Ctl>(1);
     s->sp = sl.take<float>(2 * N * F);
     s->psum_v = sl.take<float>(std::max<size_t>(s->h_vtile_seg.empty() ? 1 : s->h_vtile_seg.back(), 1) * F);
-    s->psum_c = sl.take<float>(std::max<size_t>(s->h_ctile_seg.empty() ? 1 : s->h_ctile_seg.back(), 1) * F);
+    s->psum_c = sl.take<float>(2 * std::max<size_t>(s->h_ctile_seg.empty() ? 1 : s->h_ctile_seg.back(), 1) * F);
     s->vmeta = sl.take<int32_t>(s->h_vmeta.size());
     s->vgseg = sl.take<int32_t>(s->h_vgseg.size());
     s->cmeta = sl.take<int32_t>(s->h_cmeta.size());
@@ -560,7 +560,7 @@ static bool plan_round(dsat_session* s) {
     a.N = g->N; a.C = g->C; a.G = g->G;
     a.V = s->V; a.Cs = s->Cs; a.q = s->q; a.sp = s->sp; a.lits = s->lits; a.closs4 = s->closs4;
     a.vla = s->vla; a.ncv = s->ncv; a.newv = s->newv; a.logits = s->logits;
-    a.psum_v = s->psum_v; a.psum_c = s->psum_c; a.noisy = s->in_noisy; a.ctl = s->ctl;
+    a.psum_v = s->psum_v; a.psum_c_rd = s->psum_c; a.psum_c_wr = s->psum_c; a.noisy = s->in_noisy; a.ctl = s->ctl;
     const int LDS = 40960;
     bool ok = true;
     {   // P1: [X 16x152 | Vlog 16x136 | A | B | mean]
@@ -929,6 +929,11 @@ static void enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int 
         }
         a2.round = r;
         a2.s_enable = early_exit && r > 0;   // G extra blocks: select/SAT of round r-1
+        {
+            const size_t half = std::max<size_t>(s->h_ctile_seg.empty() ? 1 : s->h_ctile_seg.back(), 1) * F;
+            a2.psum_c_wr = s->psum_c + (r & 1) * half;
+            a2.psum_c_rd = s->psum_c + ((r + 1) & 1) * half;
+        }
         a3.round = r;
         L.run(KC_ROUND_P2, [&] { (void)launch_round_p2(a2, s->p2_rb, st); });
         L.run(KC_ROUND_P3, [&] { (void)launch_round_p3(a3, st); });

@@ -163,7 +163,11 @@ struct RoundArgs {
     const int32_t *vmeta, *cmeta;     // per-tile records, TILE_META_INTS int32 each (see TileMetaDev)
     int N, C, G;
     // state and intermediates (HBM)
-    float *V, *Cs, *q, *sp, *lits, *closs4, *vla, *ncv, *newv, *logits, *psum_v, *psum_c;
+    float *V, *Cs, *q, *sp, *lits, *closs4, *vla, *ncv, *newv, *logits, *psum_v;
+    // clause column sums are read (previous round) and written (this round) by the same kernel,
+    // P2, whose workgroups are not all co-resident on large batches: two buffers, by round parity
+    const float* psum_c_rd;
+    float* psum_c_wr;
     const float* noisy;    // [N,2] noisy_num of this denoising step
     Ctl* ctl;
     float* trace_logits;   // optional [rounds,N,8]

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
     int* sIdx = sPtr + BM + 8;
     const bool staged = stage_csr(a.c_rowptr, a.c_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr,
                                   sIdx, BM * a.ld_a - (BM + 8), tid);
-    pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c, a.ncv, a.Cs, a.round == 0, sX, ldx, nullptr, 0,
+    pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.ncv, a.Cs, a.round == 0, sX, ldx, nullptr, 0,
                       sMean, tid);   // its barriers also publish sPtr / sIdx
     DSAT_STAMP(a, 1);
     // R3 + R5 + R7: half-wave hw owns rows hw, hw+16, ...; two rows are in flight at a time
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
             }
         });
         DSAT_STAMP(a, 3);
-        tile_colsums<BM>(tile_lo, C, tm, a.cl_seg, a.psum_c, stage, lds, sMean, tid);
+        tile_colsums<BM>(tile_lo, C, tm, a.cl_seg, a.psum_c_wr, stage, lds, sMean, tid);
         DSAT_STAMP(a, 4);
     }
 }

@@ -1,0 +1,109 @@
+"""``DiffusionSampler(model_path, dimacs_filename).samples(n)`` -- the reference's outer surface
+(satuniformity/DiffusionSampler.py:195-311, README.md:46-52) on the MI355X-native hot path.
+
+What runs where
+  * host (this file): DIMACS loading, replicate-instance batching, the ``dict[int -> count]``
+    of distinct satisfying assignments, the 0.5 % abort rule;
+  * device (``dsat_sample``): the whole T-step reverse diffusion of one batch -- randomized
+    rounding, R message-passing rounds per step, per-graph SAT check, theoretic reverse step,
+    freeze-on-first-solution -- with no host round trip inside the loop.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import runtime
+from .batch import Batch, make_batch, replicate_instance
+from .dimacs import DimacsFile, VariableAssignment
+from .query_sat import GraphInputs, QuerySAT
+
+# module constants of the reference (satuniformity/DiffusionSampler.py:17-21)
+use_baseline_sampling = True
+test_rounds = 32
+diffusion_steps = 32
+self_supervised = False
+max_nodes_per_batch = 20000      # config.py:35
+
+
+def diffusion(N: int, model: QuerySAT, graph_inputs: GraphInputs, seed: int = 0, early_exit: bool = True,
+              uniform=None, normal=None, labels=None, want_predictions: bool = False):
+    """``diffusion(N, model, dataset, step_data)`` (satuniformity/DiffusionSampler.py:78-191):
+    returns (mean(cum_accuracy), predictions[N_vars] in {0,1}, var_correct[N_vars])."""
+    sess = model._session(graph_inputs)
+    out = sess.sample(N, model.test_rounds, seed=seed, early_exit=early_exit, uniform=uniform, normal=normal,
+                      labels=labels, want_predictions=want_predictions)
+    gid = torch.from_numpy(graph_inputs.batch.var_graph_id.astype(np.int64)).to(out["solved"].device)
+    var_correct = out["solved"].to(torch.float32)[gid]            # :176-180
+    res = (out["solved_fraction"], out["assignment"], var_correct)
+    return res + (out["predictions"],) if want_predictions else res
+
+
+class DiffusionSampler:
+    """Same constructor and ``samples`` contract as the reference.
+
+    ``model_path``: a TF2 checkpoint directory/prefix (satuniformity/DiffusionSampler.py:215-227),
+    or an ``.npz`` written by ``diffusionsat_amd.weights.save_npz``; when nothing is found the
+    model keeps its fresh Glorot weights, as the reference does ("Checkpoint not found!").
+    ``test_solutions_multiplier_k`` etc. of the reference's dataset only size how many copies of
+    the formula are generated; here copies are generated on demand until ``n_samples`` is met.
+    """
+
+    def __init__(self, model_path: Optional[str], dimacs_filename: str, device: str = "cuda:0", seed: int = 0,
+                 rank: int = 0, world_size: int = 1):
+        self.model = QuerySAT(optimizer=None, test_rounds=test_rounds, device=device, seed=seed)
+        self.restored = bool(model_path) and self.model.load_weights(model_path)
+        test_dimacs = DimacsFile(filename=dimacs_filename)
+        test_dimacs.load()
+        self.dimacs = test_dimacs
+        self.n_vars = test_dimacs.number_of_vars()
+        self.clauses = test_dimacs.clauses()
+        if self.n_vars <= 0:
+            raise ValueError("%s: no variables" % dimacs_filename)
+        # a batch = as many copies of the formula as fit the node budget (data/dimac.py:267-293,
+        # data/diffusion_sat_instances.py:80-94)
+        self.copies_per_batch = replicate_instance(self.n_vars, self.clauses, copies=0,
+                                                   max_nodes_per_batch=max_nodes_per_batch)
+        self.batch: Batch = make_batch([(self.n_vars, self.clauses)] * self.copies_per_batch)
+        self.inputs = GraphInputs(self.batch)
+        self.seed, self.rank, self.world_size = int(seed), int(rank), int(world_size)
+        self.success_rate = 0.0
+
+    def _decode(self, assignment: np.ndarray, counts: Dict[int, int], still_needed: int):
+        """Per-graph loop of ``samples`` (:283-307): int-encode (bit i <-> x_{i+1}), re-check."""
+        total = sat = 0
+        n = self.n_vars
+        asgn = VariableAssignment(n_vars=n, clauses=self.clauses)
+        for i in range(self.copies_per_batch):
+            asgn.assign_all_from_bit_list(assignment[i * n:(i + 1) * n])
+            total += 1
+            if asgn.satisfiable():
+                sat += 1
+                key = int(asgn)
+                counts[key] = counts.get(key, 0) + 1
+                still_needed -= 1
+                if still_needed == 0:
+                    break
+        return total, sat, still_needed
+
+    def samples(self, n_samples: int) -> Dict[int, int]:
+        """:param n_samples: how many correct samples to generate
+        :return: dict: solution as int => count   (satuniformity/DiffusionSampler.py:229-311)"""
+        counts: Dict[int, int] = {}
+        total = sat = 0
+        needed = int(n_samples)
+        it = 0
+        while needed > 0:
+            if total > 0 and sat / total < 0.005:           # :261-263 too many unsat samples
+                break
+            # every batch (and every rank) draws from its own Philox sub-stream
+            seed = self.seed + 1000003 * (it * self.world_size + self.rank) + 1
+            _, assignment, _ = diffusion(diffusion_steps, self.model, self.inputs, seed=seed)
+            t, s, needed = self._decode(assignment.cpu().numpy(), counts, needed)
+            total += t
+            sat += s
+            it += 1
+        self.success_rate = sat / total if total else 0.0
+        return counts

@@ -1,0 +1,170 @@
+"""CPU tests of the oracle itself (no GPU): what pins it in the absence of reference vectors.
+
+  1. fp32 vs fp64 NumPy restatement agree (and stay apart by < 5e-5 over 32 rounds);
+  2. an independently written PyTorch restatement agrees, with the inner tape taken by
+     torch.autograd instead of the closed form (model/query_sat.py:227-246);
+  3. structural properties the reference itself checks at training time
+     (diffusion_training.py:435-484): variable permutation / polarity inversion equivariance,
+     and block-diagonal batching == running each graph alone;
+  4. the committed fixture tests/golden/step_golden.npz;
+  5. the Philox mirror against the Random123 known-answer vectors.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import draws, make_all, oracle_weights
+from oracle import philox, querysat_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "step_golden.npz")
+
+
+def _step(insts, ws, ns, rounds, seed, dt=np.float32, noisy=None, d=None, early_exit=False):
+    data = O.create_adj_matrices(insts, dt=dt)
+    n = data["adjacency_matrix"].shape[0] // 2
+    d = d or draws(n, rounds, seed=seed)
+    if noisy is None:
+        noisy = O.randomized_rounding(np.full((n, 2), 0.5, np.float32), d["uniform"])
+    w = ws if dt == np.float32 else O.cast_weights(ws, dt)
+    return O.diffusion_step(w, data, dt(ns), noisy.astype(dt), d["normal"], d["labels"], rounds,
+                            early_exit=early_exit, dt=dt, trace=True), d, noisy
+
+
+def test_fp32_vs_fp64_is_well_conditioned():
+    insts, _, _ = make_all("3sat")
+    ws = oracle_weights(0)
+    for ns in (1.0, 0.5, 1 / 32):
+        r32, d, noisy = _step(insts, ws, ns, 32, seed=1)
+        r64, _, _ = _step(insts, ws, ns, 32, seed=1, dt=np.float64, noisy=noisy, d=d)
+        errs = [np.abs(a - b).max() for a, b in zip(r32["trace"]["logits"], r64["trace"]["logits"])]
+        assert max(errs) < 5e-5, errs          # no growth over the 32 PairNorm-renormalised rounds
+        assert errs[-1] < 5 * (errs[0] + 1e-6)
+
+
+def test_torch_restatement_and_autograd_agree():
+    torch = pytest.importorskip("torch")
+    from oracle import querysat_torch as QT
+    torch.set_num_threads(2)
+    insts, _, data = make_all("ragged")
+    ws = oracle_weights(4)
+    rounds = 6
+    ref, d, noisy = _step(insts, ws, 0.4, rounds, seed=3)
+    tb = QT.TorchBatch(insts)
+    tw = QT.to_torch_weights(ws)
+    for use_autograd in (False, True):
+        out = QT.diffusion_step(tw, tb, 0.4, noisy, d["normal"], d["labels"], rounds, use_autograd=use_autograd,
+                                all_logits=True)
+        for r in range(rounds):
+            assert np.abs(out["logits_all"][r].numpy() - ref["trace"]["logits"][r]).max() < 2e-5
+        pgl = ref["trace"]["per_graph_loss"][-1]
+        srt = np.sort(pgl, axis=1)
+        clear = (srt[:, 1] - srt[:, 0]) > 1e-4
+        assert np.array_equal(out["best_map"].numpy()[clear], ref["best_map"][clear])
+
+
+def test_closed_form_gradient_matches_finite_difference():
+    """R4: d(sum exp(-A^T softplus([q;-q])))/dq in closed form vs central differences (fp64)."""
+    insts, _, data = make_all("ragged")
+    adj = data["adjacency_matrix"].astype(np.float64)
+    cl = adj.T.tocsr()
+    n = adj.shape[0] // 2
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal((n, 3))
+    closs = O.softplus_loss_adj(q, cl)
+    m = adj @ closs
+    grad = -O.sigmoid(q) * m[:n] + O.sigmoid(-q) * m[n:]
+    eps = 1e-6
+    for (i, j) in [(0, 0), (n - 1, 2), (n // 2, 1)]:
+        qp, qm = q.copy(), q.copy()
+        qp[i, j] += eps
+        qm[i, j] -= eps
+        fd = (O.softplus_loss_adj(qp, cl).sum() - O.softplus_loss_adj(qm, cl).sum()) / (2 * eps)
+        assert abs(fd - grad[i, j]) < 1e-6 * max(1, abs(fd))
+
+
+def test_block_diagonal_batching_equals_single_graphs():
+    insts, _, _ = make_all("3sat")
+    ws = oracle_weights(2)
+    rounds = 5
+    whole, d, noisy = _step(insts, ws, 0.3, rounds, seed=5)
+    off = 0
+    for n_vars, clauses in insts:
+        sl = slice(off, off + n_vars)
+        dd = {"normal": d["normal"][:, sl], "labels": d["labels"][sl], "uniform": d["uniform"][sl]}
+        alone, _, _ = _step([(n_vars, clauses)], ws, 0.3, rounds, seed=0, noisy=noisy[sl], d=dd)
+        assert np.abs(alone["logits"] - whole["logits"][sl]).max() < 2e-5
+        off += n_vars
+
+
+def test_variable_permutation_and_polarity_equivariance():
+    n, clauses = make_all("uf20")[0][0]
+    ws = oracle_weights(6)
+    rounds = 4
+    base, d, noisy = _step([(n, clauses)], ws, 0.6, rounds, seed=9)
+    # permute variables
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(n)                 # new index of old variable v is perm[v]
+    pc = [[int(np.sign(l)) * int(perm[abs(l) - 1] + 1) for l in c] for c in clauses]
+    inv = np.argsort(perm)
+    d2 = {"normal": d["normal"][:, inv], "labels": d["labels"][inv], "uniform": d["uniform"][inv]}
+    out, _, _ = _step([(n, pc)], ws, 0.6, rounds, seed=0, noisy=noisy[inv], d=d2)
+    assert np.abs(out["logits"][perm] - base["logits"]).max() < 2e-5
+
+
+def test_train_loss_ties_pick_first_map_at_noise_scale_one():
+    insts, _, _ = make_all("3sat")
+    out, _, _ = _step(insts, oracle_weights(1), 1.0, 3, seed=2)
+    assert np.all(out["trace"]["per_graph_loss"][-1] == 0)
+    assert np.all(out["best_map"] == 0)
+
+
+def test_early_exit_steps_taken():
+    insts = [(3, [[1, -1], [2, -2], [3, -3]])]
+    out, _, _ = _step(insts, oracle_weights(0), 0.5, 6, seed=0, early_exit=True)
+    assert out["steps_taken"] == 0
+    insts = [(2, [[1], [-1], [2, 1]])]
+    out, _, _ = _step(insts, oracle_weights(0), 0.5, 4, seed=0, early_exit=True)
+    assert out["steps_taken"] == 3
+
+
+def test_committed_step_fixture():
+    g = np.load(GOLD, allow_pickle=False)
+    for kind in ("3sat", "ragged"):
+        insts, _, data = make_all(kind)
+        ws = oracle_weights(5)
+        rounds = g[kind + "_normal"].shape[0]
+        out = O.diffusion_step(ws, data, g[kind + "_noise_scale"], g[kind + "_noisy"], g[kind + "_normal"],
+                               g[kind + "_labels"], rounds, early_exit=False, dt=np.float32, trace=True)
+        got = np.stack(out["trace"]["logits"])
+        assert np.abs(got - g[kind + "_round_logits_f32"]).max() < 1e-5   # BLAS summation order may differ
+        assert np.abs(got - g[kind + "_round_logits_f64"]).max() < 5e-5
+        assert np.array_equal(out["best_map"], g[kind + "_best_map"])
+
+
+def test_diffusion_and_samples_on_a_small_formula():
+    insts = [(5, [[-1, 2], [1, -2], [-3, 4, 5]])] * 3     # utils/test_AllSolutions.py formula, 14 models
+    data = O.create_adj_matrices(insts)
+    ws = oracle_weights(7)
+    T, R = 4, 3
+    d = draws(15, R, steps=T, seed=4)
+    acc, final, steps = O.diffusion(ws, data, T, d["normal"], d["labels"], d["uniform"], rounds=R, dt=np.float32,
+                                    trace=True)
+    assert final.shape == (15,) and set(np.unique(final)) <= {0.0, 1.0}
+    assert 0.0 <= acc <= 1.0 and len(steps) == T
+    counts, n_sat = O.samples_from_predictions(final, 3, 5, insts[0][1])
+    assert sum(counts.values()) == n_sat <= 3
+    # brute force model count of the known-answer formula
+    models = sum(O.satisfiable(insts[0][1], [(m >> i) & 1 for i in range(5)]) for m in range(32))
+    assert models == 14
+
+
+def test_philox_known_answers():
+    assert [int(v) for v in philox.philox4x32_10(0, 0, 0, 0, 0)] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    x = philox.philox4x32_10(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF)
+    assert [int(v) for v in x] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    z = philox.normal(1, 0, 64, 500)
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    u = philox.uniform(3, 2, 10000)
+    assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.02
+    assert set(np.unique(philox.labels(3, 2, 1000))) == {0, 1}
