@@ -15,7 +15,7 @@ torch.cuda.synchronize()
 buf = (C.c_int64 * (3 * 4096 * 8))()
 _lib.check(_lib.load().dsat_session_read_stamps(s.handle, buf, 3 * 4096 * 8))
 st = np.frombuffer(buf, dtype=np.int64).reshape(3, 4096, 8)
-names = {0: ["pairnorm+aux", "stages(out+query+lit)"], 1: ["pairnorm", "gather", "clause_mlp", "colsums"],
+names = {0: ["pairnorm+aux", "out_mlp", "query_mlp", "lit_mlp"], 1: ["pairnorm", "gather", "clause_mlp", "colsums"],
          2: ["gather", "update_mlp", "colsums"]}
 tiles = {0: (batch.n_vars + 15) // 16, 1: (batch.n_clauses + 63) // 64, 2: (batch.n_vars + 15) // 16}
 for k in range(3):
