@@ -918,6 +918,13 @@ static void enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int 
     for (int r = 0; r <= rounds; ++r) {
         a1.round = r;
         a1.tail = r == rounds;
+        const size_t half = std::max<size_t>(s->h_ctile_seg.empty() ? 1 : s->h_ctile_seg.back(), 1) * F;
+        // idle CUs of P1 finish the clause PairNorm of round r-1 (only worth it while the variable
+        // tiles leave CUs idle; otherwise P2 does it in its prologue)
+        const int vtiles = (s->g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
+        const int cn = (r > 0 && r < rounds && s->g->C > 0 && vtiles < 248 && !getenv("DSAT_NO_CN")) ? 256 - vtiles : 0;
+        a1.cn_blocks = cn;
+        a1.psum_c_rd = s->psum_c + ((r + 1) & 1) * half;   // written by P2(r-1)
         L.run(KC_ROUND_P1, [&] { (void)launch_round_p1(a1, st); });   // also produces logits of round r-1
         if (r == rounds) {
             // R15-R17 of the last round (with early exit the earlier rounds' run inside P2)
@@ -929,8 +936,8 @@ static void enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int 
         }
         a2.round = r;
         a2.s_enable = early_exit && r > 0;   // G extra blocks: select/SAT of round r-1
+        a2.cs_ready = cn > 0;
         {
-            const size_t half = std::max<size_t>(s->h_ctile_seg.empty() ? 1 : s->h_ctile_seg.back(), 1) * F;
             a2.psum_c_wr = s->psum_c + (r & 1) * half;
             a2.psum_c_rd = s->psum_c + ((r + 1) & 1) * half;
         }

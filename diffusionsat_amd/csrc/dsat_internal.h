@@ -176,6 +176,9 @@ struct RoundArgs {
     int32_t *best, *graph_unsat;
     uint8_t* assign;
     int s_enable;          // P2 only: append G blocks running select/SAT of round-1
+    int cn_blocks;         // P1 only: extra blocks that finish the clause PairNorm of round-1 (R10)
+                           //          on CUs the variable tiles leave idle; 0 = P2 does it itself
+    int cs_ready;          // P2 only: clause_state was already normalised by P1's extra blocks
     int round;             // message-passing round this launch belongs to
     int check_done;        // early exit armed: skip when ctl->done
     int tail;              // P1 only: run the PairNorm + output-MLP part and stop

@@ -245,14 +245,61 @@ __device__ void select_sat_body(int g, int ngraphs, const int32_t* __restrict__ 
                                 float* __restrict__ out_logits, uint8_t* __restrict__ assign,
                                 int32_t* __restrict__ graph_unsat, int N, int round, int set_done, float* sred);
 
+// R10 for a contiguous range of clause rows (one of `nb` extra workgroups of P1): same arithmetic
+// as pairnorm_tile, streamed; clause_state is updated in place for P2 to load.
+__device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int nb, float* sMean, int tid) {
+    const int C = a.C;
+    const int per = (C + nb - 1) / nb;
+    const int lo0 = b * per, hi0 = min(lo0 + per, C);
+    if (lo0 >= hi0) return;
+    const int sub = tid & 31, hw = tid >> 5;
+    for (int g = a.cl_gid[lo0]; g <= a.cl_gid[hi0 - 1]; ++g) {
+        const int s0 = a.cl_seg[g], s1 = a.cl_seg[g + 1];
+        const int lo = max(s0, lo0), hi = min(s1, hi0);
+        if (lo >= hi) continue;
+        if (tid < F) {
+            float m = 0.f;
+            for (int sgi = a.cgseg[g]; sgi < a.cgseg[g + 1]; ++sgi) m += a.psum_c_rd[(size_t)sgi * F + tid];
+            sMean[tid] = m * (1.f / (float)(s1 - s0));
+        }
+        __syncthreads();
+        const float4 mean = ld4(sMean + sub * 4);
+        for (int r = lo + hw; r < hi; r += NT / 32) {
+            float4 v = ld4(a.ncv + (size_t)r * F + sub * 4);
+            const float4 o4 = ld4(a.Cs + (size_t)r * F + sub * 4);
+            v.x -= mean.x; v.y -= mean.y; v.z -= mean.z; v.w -= mean.w;
+            float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+            const float rs = 1.f / sqrtf(ss * (1.f / F) + 1e-6f);
+            float4 res;
+            res.x = v.x * rs * 0.25f + 0.1f * o4.x; res.y = v.y * rs * 0.25f + 0.1f * o4.y;
+            res.z = v.z * rs * 0.25f + 0.1f * o4.z; res.w = v.w * rs * 0.25f + 0.1f * o4.w;
+            res.x = __fadd_rn(__fmul_rn(res.x, 0.2f), __fmul_rn(res.x, 0.8f));
+            res.y = __fadd_rn(__fmul_rn(res.y, 0.2f), __fmul_rn(res.y, 0.8f));
+            res.z = __fadd_rn(__fmul_rn(res.z, 0.2f), __fmul_rn(res.z, 0.8f));
+            res.w = __fadd_rn(__fmul_rn(res.w, 0.2f), __fmul_rn(res.w, 0.8f));
+            st4(a.Cs + (size_t)r * F + sub * 4, res);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------- P1
+// Blocks [0, vtiles) are variable tiles; blocks [vtiles, vtiles + cn_blocks) finish the clause
+// PairNorm of the previous round (it depends on P2(r-1) only), off P2's critical path.
 __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     if (a.check_done && a.ctl->done != 0) return;
     constexpr int BM = ROUND_BM_VAR;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.N;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int vtiles = (N + BM - 1) / BM;
+    if ((int)blockIdx.x >= vtiles) {
+        clause_norm_block(a, blockIdx.x - vtiles, a.cn_blocks, smem, tid);
+        return;
+    }
+    const int tile = xcd_tile(blockIdx.x, vtiles);
     const int tile_lo = tile * BM;
     float* sX = smem + a.off_x;
     float* sVlog = smem + a.off_vlog;
@@ -343,8 +390,20 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
     int* sIdx = sPtr + BM + 8;
     const bool staged = stage_csr(a.c_rowptr, a.c_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr,
                                   sIdx, BM * a.ld_a - (BM + 8), tid);
-    pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.ncv, a.Cs, a.round == 0, sX, ldx, nullptr, 0,
-                      sMean, tid);   // its barriers also publish sPtr / sIdx
+    if (a.cs_ready && a.round > 0) {   // R10 was finished by P1's extra blocks: just load the rows
+        const int sub = tid & 31, hw = tid >> 5;
+#pragma unroll
+        for (int kq = 0; kq < ROWS; ++kq) {
+            const int r = hw + kq * (NT / 32);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile_lo + r < tile_hi) v = ld4(a.Cs + (size_t)(tile_lo + r) * F + sub * 4);
+            st4(sX + r * ldx + sub * 4, v);
+        }
+        __syncthreads();
+    } else {
+        pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.ncv, a.Cs, a.round == 0, sX, ldx,
+                          nullptr, 0, sMean, tid);   // its barriers also publish sPtr / sIdx
+    }
     DSAT_STAMP(a, 1);
     // R3 + R5 + R7: half-wave hw owns rows hw, hw+16, ...; two rows are in flight at a time
     {
@@ -692,7 +751,7 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
 }  // namespace
 
 hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st) {
-    const int tiles = (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
+    const int tiles = (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + a.cn_blocks;
     hipLaunchKernelGGL(round_p1_kernel, dim3(tiles), dim3(NT), 0, st, a);
     return hipGetLastError();
 }
