@@ -535,6 +535,7 @@ static ChainSpec make_chain(const std::vector<PackedLayer>& layers, int rb) {
         c.L[l].kblocks = layers[l].kblocks();
         c.L[l].ntiles = layers[l].ntiles();
         c.L[l].tpw = pick_tpw(c.L[l].ntiles, ROUND_NWAVES, max_tpw_for_rb(rb));
+        c.L[l].tpw_half = pick_tpw(c.L[l].ntiles, ROUND_NWAVES / 2, max_tpw_for_rb(rb));
     }
     return c;
 }
@@ -1143,6 +1144,7 @@ static int op_mlp_fused(dsat_session* s, int mlp, const float* x, int rows, floa
         a.L[l].kblocks = layers[l].kblocks();
         a.L[l].ntiles = layers[l].ntiles();
         a.L[l].tpw = pick_tpw(a.L[l].ntiles, nwaves, max_tpw_for_rb(rb));
+        a.L[l].tpw_half = a.L[l].tpw;
         if (l + 1 < a.nlayers) {
             if (l & 1) w0 = std::max(w0, layers[l].npad); else w1 = std::max(w1, layers[l].npad);
         }

@@ -134,6 +134,7 @@ struct ChainLayer {
     const float4* wp;   // fragment-ordered weights
     const float* bias;
     int kblocks, ntiles, tpw;
+    int tpw_half;       // tiles per wave when only half of the workgroup's waves run this layer
 };
 struct ChainArgs {
     ChainLayer L[4];

@@ -224,6 +224,33 @@ __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, 
     }
 }
 
+// Two independent 2-layer chains side by side: waves [0, NW/2) run chain A, the others chain B
+// (each on its own hidden buffer), sharing the two layer barriers.  Small chains cannot keep
+// eight waves busy (variables_output has 8 + 2 column tiles), so running them one after the
+// other pays their fixed per-layer latency twice.
+template <typename StoreA, typename StoreB>
+__device__ __forceinline__ void run_chain_pair(const ChainSpec& ma, const float* sInA, int ldinA, float* bufA, int ldA,
+                                               const ChainSpec& mb, const float* sInB, int ldinB, float* bufB, int ldB,
+                                               int wave, int lane, StoreA&& storeA, StoreB&& storeB) {
+    constexpr int H = ROUND_NWAVES / 2;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform for the compiler: the
+    if (wv < H) {                                          // weight base must stay in SGPRs
+        dense_layer<1, H>(sInA, ldinA, ma.L[0].kblocks, ma.L[0].wp, ma.L[0].bias, ma.L[0].ntiles, ma.L[0].tpw_half, 1,
+                          wv, lane, [=](int row, int col, float v) { bufA[row * ldA + col] = v; });
+        __syncthreads();
+        dense_layer<1, H>(bufA, ldA, ma.L[1].kblocks, ma.L[1].wp, ma.L[1].bias, ma.L[1].ntiles, ma.L[1].tpw_half, 0,
+                          wv, lane, storeA);
+        __syncthreads();
+    } else {
+        dense_layer<1, H>(sInB, ldinB, mb.L[0].kblocks, mb.L[0].wp, mb.L[0].bias, mb.L[0].ntiles, mb.L[0].tpw_half, 1,
+                          wv - H, lane, [=](int row, int col, float v) { bufB[row * ldB + col] = v; });
+        __syncthreads();
+        dense_layer<1, H>(bufB, ldB, mb.L[1].kblocks, mb.L[1].wp, mb.L[1].bias, mb.L[1].ntiles, mb.L[1].tpw_half, 0,
+                          wv - H, lane, storeB);
+        __syncthreads();
+    }
+}
+
 // CSR entries of the tile's rows -> LDS (entry ranges of consecutive rows are contiguous):
 // sPtr[i] = rowptr[row_lo + i] - e_base for i = 0..nrows, sIdx[k] = idx[e_base + k].
 // Returns false (nothing staged) when the range does not fit `cap` entries.
@@ -318,31 +345,37 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
                       ldv, sMean, tid);
     DSAT_STAMP(a, 1);
 
-    if (a.round > 0) {   // R14: logits of the previous round from the pre-mix state
-        float* lg = a.logits;
-        float* tr = a.trace_logits != nullptr ? a.trace_logits + (size_t)(a.round - 1) * N * LOGIT_MAPS : nullptr;
-        run_chain<1>(a.mout, sVlog, ldv, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float v) {
-            const int n = tile_lo + row;
-            if (n < N && col < LOGIT_MAPS) {
-                lg[(size_t)n * LOGIT_MAPS + col] = v;
-                if (tr != nullptr) tr[(size_t)n * LOGIT_MAPS + col] = v;
-            }
-        });
-    }
-    DSAT_STAMP(a, 2);
-    if (a.tail) return;
-
-    {   // R2: query = variables_query(v1); softplus(+-query) feeds the clause gather (loss/sat.py:132-133)
-        float* q = a.q;
-        float* sp = a.sp;
-        run_chain<1>(a.mq, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float v) {
-            const int n = tile_lo + row;
-            if (n < N && col < F) {
-                q[(size_t)n * F + col] = v;
-                sp[(size_t)n * F + col] = softplus_f(v);
-                sp[(size_t)(N + n) * F + col] = softplus_f(-v);
-            }
-        });
+    float* lg = a.logits;
+    float* tr = a.trace_logits != nullptr && a.round > 0
+                    ? a.trace_logits + (size_t)(a.round - 1) * N * LOGIT_MAPS : nullptr;
+    float* q = a.q;
+    float* sp = a.sp;
+    // R14: logits of the previous round from the pre-mix state
+    auto store_logits = [=](int row, int col, float v) {
+        const int n = tile_lo + row;
+        if (n < N && col < LOGIT_MAPS) {
+            lg[(size_t)n * LOGIT_MAPS + col] = v;
+            if (tr != nullptr) tr[(size_t)n * LOGIT_MAPS + col] = v;
+        }
+    };
+    // R2: query = variables_query(v1); softplus(+-query) feeds the clause gather (loss/sat.py:132-133)
+    auto store_query = [=](int row, int col, float v) {
+        const int n = tile_lo + row;
+        if (n < N && col < F) {
+            q[(size_t)n * F + col] = v;
+            sp[(size_t)n * F + col] = softplus_f(v);
+            sp[(size_t)(N + n) * F + col] = softplus_f(-v);
+        }
+    };
+    if (a.round > 0 && !a.tail && a.mout.nlayers == 2 && a.mq.nlayers == 2) {
+        run_chain_pair(a.mout, sVlog, ldv, sA, a.ld_a, a.mq, sX, ldx, sB, a.ld_b, wave, lane, store_logits,
+                       store_query);
+        DSAT_STAMP(a, 2);
+    } else {
+        if (a.round > 0) run_chain<1>(a.mout, sVlog, ldv, sA, a.ld_a, sB, a.ld_b, wave, lane, store_logits);
+        DSAT_STAMP(a, 2);
+        if (a.tail) return;
+        run_chain<1>(a.mq, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, store_query);
     }
     DSAT_STAMP(a, 3);
     {   // R6: literals = [lit_mlp(v1)[:, :128] ; [:, 128:]]
