@@ -170,6 +170,14 @@ def main():
             }
             kern_name = {"round_p1_var_query_lit": "round_p1_kernel", "round_p2_clause": "round_p2_kernel<4>",
                          "round_p3_var_update": "round_p3_kernel"}
+            # HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 cannot run inside
+            # this process); null when the file is absent
+            traffic = {}
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                    traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
+            except (OSError, KeyError, ValueError):
+                pass
             roofs = {}
             for k, fl in per_launch.items():
                 if k in prof and prof[k]["launches"] > 0:
@@ -177,7 +185,8 @@ def main():
                     ach = fl / (us * 1e-6) / 1e12
                     roofs[k] = {"bound": "mfma", "kernel": kern_name[k], "achieved": ach,
                                 "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS,
-                                "traffic": None, "avg_launch_us": us,
+                                "traffic": traffic.get(k) if (args.graphs, args.vars) == (31, 100) else None,
+                                "avg_launch_us": us,
                                 "launches_per_step": prof[k]["launches"] / steps_prof,
                                 "algorithmic_flops_per_launch": fl,
                                 "share_of_device_time": us * prof[k]["launches"] / steps_prof / all_us}
