@@ -438,6 +438,7 @@ struct dsat_session {
     int profile = 0;
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, int>> ev_used;  // (class, pool index of start)
+    double prof_overhead_us = 0.0;
     double prof_us[KC_COUNT];
     int64_t prof_n[KC_COUNT];
 };
@@ -742,11 +743,35 @@ struct Launcher {
 
 static int collect_profile(dsat_session* s, hipStream_t st) {
     DSAT_HIP(hipStreamSynchronize(st));
+    // An event pair costs time even with nothing between the two records (the markers are
+    // packets of their own).  Calibrate that on this stream and take it off every bracket, so the
+    // per-kernel averages agree with rocprofv3's kernel durations.
+    double overhead_us = 0.0;
+    {
+        constexpr int NCAL = 16;
+        hipEvent_t ev[2 * NCAL];
+        for (auto& e : ev) DSAT_HIP(hipEventCreate(&e));
+        for (int i = 0; i < NCAL; ++i) {
+            DSAT_HIP(hipEventRecord(ev[2 * i], st));
+            DSAT_HIP(hipEventRecord(ev[2 * i + 1], st));
+        }
+        DSAT_HIP(hipStreamSynchronize(st));
+        std::vector<double> v;
+        for (int i = 0; i < NCAL; ++i) {
+            float ms = 0.f;
+            DSAT_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            v.push_back((double)ms * 1e3);
+        }
+        std::sort(v.begin(), v.end());
+        overhead_us = v[NCAL / 2];
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    s->prof_overhead_us = overhead_us;
     for (int i = 0; i < KC_COUNT; ++i) { s->prof_us[i] = 0; s->prof_n[i] = 0; }
     for (auto& u : s->ev_used) {
         float ms = 0.f;
         DSAT_HIP(hipEventElapsedTime(&ms, s->ev_pool[u.second], s->ev_pool[u.second + 1]));
-        s->prof_us[u.first] += (double)ms * 1e3;
+        s->prof_us[u.first] += std::max(0.0, (double)ms * 1e3 - overhead_us);
         s->prof_n[u.first] += 1;
     }
     s->ev_used.clear();

@@ -161,3 +161,28 @@ def test_facade_query_sat_and_sampler(rt, tmp_path):
     DimacsFile(str(bad), clauses=[[1], [-1], [2, 1]]).store()
     smp2 = DiffusionSampler(None, str(bad))
     assert smp2.samples(3) == {} and smp2.success_rate == 0.0
+
+
+def test_irregular_degree_graph_matches_oracle(rt):
+    """Config-5-like stress: clause lengths 2..8, power-law literal degrees (hundreds of clauses on
+    the busiest literals, far beyond the LDS-staged CSR capacity of a 16-variable tile, so the
+    un-staged gather path runs too).  3 rounds against the oracle."""
+    from diffusionsat_amd.batch import make_batch
+    from diffusionsat_amd.instances import irregular_cnf
+    insts = [irregular_cnf(1500, 9000, seed=5, zipf_a=1.1)[:2], irregular_cnf(700, 3000, seed=6)[:2]]
+    batch = make_batch(insts)
+    data = O.create_adj_matrices(insts)
+    deg = np.asarray(data["adjacency_matrix"].sum(axis=1)).ravel()
+    assert deg.max() > 600                       # really irregular
+    ws = oracle_weights(4)
+    rounds = 3
+    d = draws(batch.n_vars, rounds, seed=8)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.3), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32, trace=True)
+    s = rt.Session(rt.Graph(batch), rt.Weights(ws), max_rounds=rounds)
+    out = s.diffusion_step(0.3, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds, early_exit=False,
+                           want_logits=True, want_round_logits=True)
+    got = out["round_logits"].cpu().numpy()
+    for r in range(rounds):
+        assert np.abs(got[r] - ref["trace"]["logits"][r]).max() < 5e-4, r
