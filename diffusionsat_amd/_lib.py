@@ -46,6 +46,8 @@ SIGNATURES = {
     "dsat_session_set_graph_replay": (C.c_int, [_vp, _i32]),
     "dsat_diffusion_step": (C.c_int, [_vp, _f32, _vp, _vp, _vp, _u64, _u32, _i32, _i32,
                                        _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dsat_diffusion_step_self": (C.c_int, [_vp, _f32, _vp, _vp, _vp, _vp, _u64, _u32, _i32, _i32,
+                                            _vp, _vp, _vp, _vp, _vp, _vp]),
     "dsat_sample": (C.c_int, [_vp, _i32, _i32, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.POINTER(_f32), _vp]),
     "dsat_op_mlp": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp]),

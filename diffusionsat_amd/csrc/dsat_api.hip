@@ -417,7 +417,7 @@ struct dsat_session {
     float *pv, *pc, *pgl, *out_logits;
     int32_t *best, *graph_unsat, *labels, *in_labels, *fixed_step;
     uint8_t *assign, *cum_acc;
-    float *in_noisy, *in_normal, *x0, *x1, *x_fixed, *scratch;
+    float *in_noisy, *in_normal, *in_denoised, *x0, *x1, *x_fixed, *scratch;
     Ctl* ctl;
     int nch_v = 1, nch_c = 1;
     // fused round kernels (kernels_round.hip)
@@ -468,6 +468,7 @@ static void carve(dsat_session* s, Slab& sl) {
     s->labels = sl.take<int32_t>(N); s->in_labels = sl.take<int32_t>(N); s->fixed_step = sl.take<int32_t>(G);
     s->assign = sl.take<uint8_t>(N); s->cum_acc = sl.take<uint8_t>(G);
     s->in_noisy = sl.take<float>(N * 2); s->in_normal = sl.take<float>(R * N * 4);
+    s->in_denoised = sl.take<float>(N);
     s->x0 = sl.take<float>(N); s->x1 = sl.take<float>(N); s->x_fixed = sl.take<float>(N);
     // scratch for the single-operator entry points: packed MLP input, widest case
     size_t max_k = 0;
@@ -1016,7 +1017,7 @@ static Ctl base_ctl(float noise_scale, uint32_t step, int n_steps, int rounds, u
     return c;
 }
 
-extern "C" int dsat_diffusion_step(dsat_session* s, float noise_scale, const float* noisy_num,
+static int diffusion_step_impl(dsat_session* s, float noise_scale, const float* noisy_num, const float* denoised,
                                     const float* normal, const int32_t* labels, uint64_t seed,
                                     uint32_t step_index, int32_t rounds, int32_t early_exit,
                                     float* logits_out, float* logits_rounds_out, float* prediction_out,
@@ -1036,6 +1037,10 @@ extern "C" int dsat_diffusion_step(dsat_session* s, float noise_scale, const flo
                                 hipMemcpyDeviceToDevice, st));
         c.inj_normal = s->in_normal;
     }
+    if (denoised) {
+        DSAT_HIP(hipMemcpyAsync(s->in_denoised, denoised, N * sizeof(float), hipMemcpyDeviceToDevice, st));
+        c.denoised = s->in_denoised;
+    }
     if (labels) {
         DSAT_HIP(hipMemcpyAsync(s->in_labels, labels, N * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         c.inj_labels = s->in_labels;
@@ -1052,6 +1057,27 @@ extern "C" int dsat_diffusion_step(dsat_session* s, float noise_scale, const flo
         DSAT_HIP(hipMemcpyAsync(steps_taken_out, &s->ctl->steps_taken, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     if (s->profile) return collect_profile(s, st);
     return DSAT_OK;
+}
+
+extern "C" int dsat_diffusion_step(dsat_session* s, float noise_scale, const float* noisy_num,
+                                    const float* normal, const int32_t* labels, uint64_t seed,
+                                    uint32_t step_index, int32_t rounds, int32_t early_exit,
+                                    float* logits_out, float* logits_rounds_out, float* prediction_out,
+                                    int32_t* best_map_out, int32_t* steps_taken_out, void* stream) {
+    return diffusion_step_impl(s, noise_scale, noisy_num, nullptr, normal, labels, seed, step_index, rounds,
+                               early_exit, logits_out, logits_rounds_out, prediction_out, best_map_out,
+                               steps_taken_out, stream);
+}
+
+extern "C" int dsat_diffusion_step_self(dsat_session* s, float noise_scale, const float* noisy_num,
+                                         const float* denoised_num, const float* normal, const int32_t* labels,
+                                         uint64_t seed, uint32_t step_index, int32_t rounds, int32_t early_exit,
+                                         float* logits_out, float* logits_rounds_out, float* prediction_out,
+                                         int32_t* best_map_out, int32_t* steps_taken_out, void* stream) {
+    DSAT_REQUIRE(denoised_num != nullptr, DSAT_E_INVALID, "dsat_diffusion_step_self: denoised_num is required");
+    return diffusion_step_impl(s, noise_scale, noisy_num, denoised_num, normal, labels, seed, step_index, rounds,
+                               early_exit, logits_out, logits_rounds_out, prediction_out, best_map_out,
+                               steps_taken_out, stream);
 }
 
 extern "C" int dsat_sample(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed, int32_t early_exit,

@@ -125,6 +125,7 @@ struct Ctl {
     int64_t labels_step_stride;
     int64_t uniform_step_stride;
     float* pred_steps_out;       // optional [T,N] record of every step's prediction
+    const float* denoised;       // optional [N]: self-conditioning input of diffusion_step_self (query_sat.py:217-218)
 };
 
 void launch_gemm(const GemmArgs& a, const int* done, hipStream_t st);

@@ -147,8 +147,10 @@ __global__ __launch_bounds__(256) void aux_kernel(float* __restrict__ aux, int N
     }
     float* o = aux + i * AUX_W;
     st4(o, make_float4(z[0], z[1], z[2], z[3]));
-    st4(o + 4, make_float4(noisy_num[2 * n], noisy_num[2 * n + 1], ctl->noise_scale, 0.f));
-    st4(o + 8, make_float4(0.f, 0.f, 0.f, 0.f));
+    float d0 = 0.f, d1 = 0.f;
+    if (ctl->denoised != nullptr) { d0 = ctl->denoised[n]; d1 = 1.f - d0; }   // query_sat.py:218
+    st4(o + 4, make_float4(noisy_num[2 * n], noisy_num[2 * n + 1], ctl->noise_scale, d0));
+    st4(o + 8, make_float4(d1, 0.f, 0.f, 0.f));
     st4(o + 12, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 void launch_aux(float* aux, int N, int rounds, const float* noisy_num, const Ctl* ctl, hipStream_t st) {

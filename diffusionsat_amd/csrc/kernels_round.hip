@@ -40,7 +40,7 @@ __device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + lo
 // [normal(4) | noisy_num(2) | noise_scale | 0 ...] = the non-state columns of v1 (:214-219, :239)
 __device__ __forceinline__ void write_aux_row(float* dst, const Ctl* ctl, const float* noisy, int n, int N,
                                               int round, bool valid) {
-    float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f, n0 = 0.f, n1 = 0.f, ns = 0.f;
+    float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f, n0 = 0.f, n1 = 0.f, ns = 0.f, d0 = 0.f, d1 = 0.f;
     if (valid) {
         if (ctl->inj_normal != nullptr) {
             const float4 v = ld4(ctl->inj_normal + ctl->normal_step_stride * ctl->step + ((size_t)round * N + n) * 4);
@@ -52,10 +52,11 @@ __device__ __forceinline__ void write_aux_row(float* dst, const Ctl* ctl, const 
             box_muller(x.z, x.w, z2, z3);
         }
         n0 = noisy[2 * n]; n1 = noisy[2 * n + 1]; ns = ctl->noise_scale;
+        if (ctl->denoised != nullptr) { d0 = ctl->denoised[n]; d1 = 1.f - d0; }   // :218
     }
     st4(dst, make_float4(z0, z1, z2, z3));
-    st4(dst + 4, make_float4(n0, n1, ns, 0.f));
-    st4(dst + 8, make_float4(0.f, 0.f, 0.f, 0.f));
+    st4(dst + 4, make_float4(n0, n1, ns, d0));
+    st4(dst + 8, make_float4(d1, 0.f, 0.f, 0.f));
     st4(dst + 12, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 

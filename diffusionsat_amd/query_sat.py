@@ -140,7 +140,7 @@ class QuerySAT:
     # -- the tf.function entry points on the sampling path ---------------------------------
     def diffusion_step(self, adj_matrix: GraphInputs, clauses_graph=None, variables_graph=None, solutions=None,
                        noise_scale: float = 1.0, noisy_num: torch.Tensor = None, *, normal=None, labels=None,
-                       early_exit=True):
+                       early_exit=True, denoised_num=None):
         """model/query_sat.py:467-481.  ``adj_matrix`` carries the batch (``GraphInputs``);
         ``clauses_graph`` / ``variables_graph`` / ``solutions`` are accepted for signature
         compatibility (the graph object already holds the memberships; solutions are unused at
@@ -150,9 +150,18 @@ class QuerySAT:
         self._calls += 1
         out = sess.diffusion_step(float(noise_scale), noisy_num.contiguous(), normal=normal, labels=labels,
                                   seed=self._seed, step_index=self._calls, rounds=self.test_rounds,
-                                  early_exit=early_exit)
+                                  early_exit=early_exit,
+                                  denoised=None if denoised_num is None else denoised_num.reshape(-1).contiguous())
         return {"steps_taken": out["steps_taken"], "loss": torch.zeros((), device=self.device),
                 "prediction": out["prediction"]}
+
+    def diffusion_step_self(self, adj_matrix: GraphInputs, clauses_graph=None, variables_graph=None,
+                            solutions=None, noise_scale: float = 1.0, noisy_num: torch.Tensor = None,
+                            denoised_num: torch.Tensor = None, **kw):
+        """model/query_sat.py:483-498: ``denoised_num`` [N,1] is the previous step's
+        sigmoid(prediction) (satuniformity/DiffusionSampler.py:50-59)."""
+        return self.diffusion_step(adj_matrix, clauses_graph, variables_graph, solutions, noise_scale, noisy_num,
+                                   denoised_num=denoised_num, **kw)
 
     def predict_step(self, adj_matrix: GraphInputs, clauses_graph=None, variables_graph=None, solutions=None):
         """model/query_sat.py:419-451 with prediction_tries == 1: ``call(training=False)`` where

@@ -112,7 +112,7 @@ class Session:
     # -- the hot path ----------------------------------------------------------------
     def diffusion_step(self, noise_scale: float, noisy_num: torch.Tensor, normal=None, labels=None,
                        seed: int = 0, step_index: int = 0, rounds: int = 32, early_exit: bool = True,
-                       want_logits: bool = False, want_round_logits: bool = False):
+                       want_logits: bool = False, want_round_logits: bool = False, denoised=None):
         lib = _lib.load()
         n, g = self.graph.n_vars, self.graph.n_graphs
         dev = self.device
@@ -121,11 +121,16 @@ class Session:
         rlog = torch.zeros(rounds, n, 8, dtype=torch.float32, device=dev) if want_round_logits else None
         best = torch.empty(g, dtype=torch.int32, device=dev)
         steps = torch.empty(1, dtype=torch.int32, device=dev)
-        _lib.check(lib.dsat_diffusion_step(
-            self.handle, float(noise_scale), _ptr(noisy_num, torch.float32, 2 * n, "noisy_num"),
-            _ptr(normal, torch.float32, rounds * n * 4, "normal"), _ptr(labels, torch.int32, n, "labels"),
-            int(seed), int(step_index), int(rounds), int(bool(early_exit)),
-            _ptr(logits), _ptr(rlog), _ptr(pred), _ptr(best), _ptr(steps), _stream()))
+        common = (_ptr(normal, torch.float32, rounds * n * 4, "normal"), _ptr(labels, torch.int32, n, "labels"),
+                  int(seed), int(step_index), int(rounds), int(bool(early_exit)),
+                  _ptr(logits), _ptr(rlog), _ptr(pred), _ptr(best), _ptr(steps), _stream())
+        if denoised is None:
+            _lib.check(lib.dsat_diffusion_step(
+                self.handle, float(noise_scale), _ptr(noisy_num, torch.float32, 2 * n, "noisy_num"), *common))
+        else:
+            _lib.check(lib.dsat_diffusion_step_self(
+                self.handle, float(noise_scale), _ptr(noisy_num, torch.float32, 2 * n, "noisy_num"),
+                _ptr(denoised, torch.float32, n, "denoised_num"), *common))
         return {"prediction": pred, "logits": logits, "round_logits": rlog, "best_map": best,
                 "steps_taken": steps}
 

@@ -135,6 +135,15 @@ int dsat_diffusion_step(dsat_session* s, float noise_scale, const float* noisy_n
                         float* logits_out, float* logits_rounds_out, float* prediction_out,
                         int32_t* best_map_out, int32_t* steps_taken_out, void* stream);
 
+/* QuerySAT.diffusion_step_self (model/query_sat.py:483-498): the same step with the
+ * self-conditioning input `denoised_num` dev [N] (the previous step's sigmoid(prediction));
+ * the model sees [denoised, 1 - denoised] in place of the two zero columns (:217-218). */
+int dsat_diffusion_step_self(dsat_session* s, float noise_scale, const float* noisy_num,
+                             const float* denoised_num, const float* normal, const int32_t* labels,
+                             uint64_t seed, uint32_t step_index, int32_t rounds, int32_t early_exit,
+                             float* logits_out, float* logits_rounds_out, float* prediction_out,
+                             int32_t* best_map_out, int32_t* steps_taken_out, void* stream);
+
 /* T denoising steps around dsat_diffusion_step = diffusion()
  * (satuniformity/DiffusionSampler.py:78-191) with use_baseline_sampling=True,
  * self_supervised=False (:17-21), entirely on the device: randomized rounding

@@ -339,11 +339,12 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
 
 
 def diffusion_step(weights, data, noise_scale, noisy_num, normal, labels, rounds=32,
-                   early_exit=True, dt=np.float32, trace=False):
+                   early_exit=True, dt=np.float32, trace=False, denoised_num=None):
     """model/query_sat.py:467-481 (``QuerySAT.diffusion_step``): labels=None at the
     call site means random labels (:145); they are the explicit ``labels`` here."""
+    # denoised_num [N,1]: QuerySAT.diffusion_step_self (model/query_sat.py:483-498)
     return query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds,
-                          early_exit=early_exit, dt=dt, trace=trace)
+                          early_exit=early_exit, dt=dt, trace=trace, denoised_num=denoised_num)
 
 
 # --------------------------------------------------------------------------- sampler

@@ -227,3 +227,29 @@ def test_device_rng_matches_philox_mirror(rt):
     assert np.array_equal(labels.cpu().numpy(), ref_l)
     assert np.array_equal(uniform.cpu().numpy(), ref_u)
     _close(normal.cpu().numpy(), ref_n, 1e-5, 1e-5)
+
+
+def test_diffusion_step_self_conditioning(rt):
+    """QuerySAT.diffusion_step_self (query_sat.py:483-498): denoised_num enters v1 as
+    [denoised, 1 - denoised]; fused and per-layer paths against the oracle."""
+    import os
+    _, batch, data = make_all("3sat")
+    ws = oracle_weights(6)
+    rounds = 6
+    d = draws(batch.n_vars, rounds, seed=13)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, dtype=np.float32), d["uniform"])
+    den = np.random.default_rng(3).random((batch.n_vars, 1)).astype(np.float32)
+    ref = O.diffusion_step(ws, data, np.float32(0.4), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32, denoised_num=den)
+    plain = O.diffusion_step(ws, data, np.float32(0.4), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                             dt=np.float32)
+    assert np.abs(ref["logits"] - plain["logits"]).max() > 1e-3          # the input matters
+    for fused in ("1", "0"):
+        os.environ["DSAT_FUSED"] = fused
+        try:
+            s = _session(rt, batch, ws, max_rounds=rounds)
+        finally:
+            os.environ.pop("DSAT_FUSED", None)
+        out = s.diffusion_step(0.4, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds,
+                               early_exit=False, want_logits=True, denoised=_dev(den.reshape(-1)))
+        _close(out["logits"].cpu().numpy(), ref["logits"], 0, LOGIT_TOL)
