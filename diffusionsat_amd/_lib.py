@@ -50,6 +50,8 @@ SIGNATURES = {
                                             _vp, _vp, _vp, _vp, _vp, _vp]),
     "dsat_sample": (C.c_int, [_vp, _i32, _i32, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.POINTER(_f32), _vp]),
+    "dsat_sample_self": (C.c_int, [_vp, _i32, _i32, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                              C.POINTER(_f32), _vp]),
     "dsat_op_mlp": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp]),
     "dsat_op_mlp_ex": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "dsat_bench_mlp": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_double), _vp]),

@@ -1080,10 +1080,10 @@ extern "C" int dsat_diffusion_step_self(dsat_session* s, float noise_scale, cons
                                steps_taken_out, stream);
 }
 
-extern "C" int dsat_sample(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed, int32_t early_exit,
-                            const float* uniform, const float* normal, const int32_t* labels,
-                            uint8_t* assignment_out, uint8_t* solved_out, float* prediction_steps_out,
-                            float* solved_fraction_out, void* stream) {
+static int sample_impl(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed, int32_t early_exit,
+                       const float* uniform, const float* normal, const int32_t* labels,
+                       uint8_t* assignment_out, uint8_t* solved_out, float* prediction_steps_out,
+                       float* solved_fraction_out, void* stream, bool self_conditioning) {
     DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_sample: null session");
     DSAT_REQUIRE(n_steps >= 1 && n_steps <= (1 << 20), DSAT_E_INVALID, "dsat_sample: n_steps out of range");
     DSAT_REQUIRE(rounds >= 1 && rounds <= s->max_rounds, DSAT_E_INVALID,
@@ -1097,6 +1097,9 @@ extern "C" int dsat_sample(dsat_session* s, int32_t n_steps, int32_t rounds, uin
     c.inj_labels = labels; c.labels_step_stride = (int64_t)N;
     c.inj_uniform = uniform; c.uniform_step_stride = (int64_t)N;
     c.pred_steps_out = prediction_steps_out;
+    if (self_conditioning) {   // predictions of step t-1 feed step t; step 0 runs without (:93, :110-117)
+        c.denoised = s->in_denoised; c.denoised_wr = s->in_denoised; c.denoised_from_step = 1;
+    }
     launch_ctl_set(s->ctl, c, st);
     launch_sample_init(s->x0, s->x1, g->N, s->fixed_step, s->cum_acc, g->G, s->ctl, st);
     for (int t = 0; t < n_steps; ++t) {
@@ -1118,6 +1121,22 @@ extern "C" int dsat_sample(dsat_session* s, int32_t n_steps, int32_t rounds, uin
         *solved_fraction_out = (float)(acc / (double)g->G);
     }
     return DSAT_OK;
+}
+
+extern "C" int dsat_sample(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed, int32_t early_exit,
+                            const float* uniform, const float* normal, const int32_t* labels,
+                            uint8_t* assignment_out, uint8_t* solved_out, float* prediction_steps_out,
+                            float* solved_fraction_out, void* stream) {
+    return sample_impl(s, n_steps, rounds, seed, early_exit, uniform, normal, labels, assignment_out, solved_out,
+                       prediction_steps_out, solved_fraction_out, stream, false);
+}
+
+extern "C" int dsat_sample_self(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed,
+                                 int32_t early_exit, const float* uniform, const float* normal,
+                                 const int32_t* labels, uint8_t* assignment_out, uint8_t* solved_out,
+                                 float* prediction_steps_out, float* solved_fraction_out, void* stream) {
+    return sample_impl(s, n_steps, rounds, seed, early_exit, uniform, normal, labels, assignment_out, solved_out,
+                       prediction_steps_out, solved_fraction_out, stream, true);
 }
 
 // ============================================================================ single operators

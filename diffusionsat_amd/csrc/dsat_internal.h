@@ -126,6 +126,8 @@ struct Ctl {
     int64_t uniform_step_stride;
     float* pred_steps_out;       // optional [T,N] record of every step's prediction
     const float* denoised;       // optional [N]: self-conditioning input of diffusion_step_self (query_sat.py:217-218)
+    float* denoised_wr;          // sampler with self_supervised: sigmoid(prediction) of this step (DiffusionSampler.py:110-113)
+    uint32_t denoised_from_step; // the input is used from this step on (the sampler's first step has none)
 };
 
 void launch_gemm(const GemmArgs& a, const int* done, hipStream_t st);

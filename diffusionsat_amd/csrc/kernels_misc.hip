@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void aux_kernel(float* __restrict__ aux, int N
     float* o = aux + i * AUX_W;
     st4(o, make_float4(z[0], z[1], z[2], z[3]));
     float d0 = 0.f, d1 = 0.f;
-    if (ctl->denoised != nullptr) { d0 = ctl->denoised[n]; d1 = 1.f - d0; }   // query_sat.py:218
+    if (ctl->denoised != nullptr && ctl->step >= ctl->denoised_from_step) { d0 = ctl->denoised[n]; d1 = 1.f - d0; }   // query_sat.py:218
     st4(o + 4, make_float4(noisy_num[2 * n], noisy_num[2 * n + 1], ctl->noise_scale, d0));
     st4(o + 8, make_float4(d1, 0.f, 0.f, 0.f));
     st4(o + 12, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -389,6 +389,7 @@ __global__ void sample_post_kernel(float* __restrict__ x0, float* __restrict__ x
     const float logit = pred[n];
     const float p = sigmoid_f(logit);
     if (ctl->pred_steps_out != nullptr) ctl->pred_steps_out[(size_t)t * N + n] = logit;
+    if (ctl->denoised_wr != nullptr) ctl->denoised_wr[n] = p;
     // reverse_distribution_step_theoretic(x, [1-p, p], noise_scale, 1/N)   (:29-37)
     const float t1 = powf((float)nsd, 0.5f);
     const double rem = nsd - inc;

@@ -52,7 +52,7 @@ __device__ __forceinline__ void write_aux_row(float* dst, const Ctl* ctl, const 
             box_muller(x.z, x.w, z2, z3);
         }
         n0 = noisy[2 * n]; n1 = noisy[2 * n + 1]; ns = ctl->noise_scale;
-        if (ctl->denoised != nullptr) { d0 = ctl->denoised[n]; d1 = 1.f - d0; }   // :218
+        if (ctl->denoised != nullptr && ctl->step >= ctl->denoised_from_step) { d0 = ctl->denoised[n]; d1 = 1.f - d0; }   // :218
     }
     st4(dst, make_float4(z0, z1, z2, z3));
     st4(dst + 4, make_float4(n0, n1, ns, d0));

@@ -34,7 +34,8 @@ def diffusion(N: int, model: QuerySAT, graph_inputs: GraphInputs, seed: int = 0,
     returns (mean(cum_accuracy), predictions[N_vars] in {0,1}, var_correct[N_vars])."""
     sess = model._session(graph_inputs)
     out = sess.sample(N, model.test_rounds, seed=seed, early_exit=early_exit, uniform=uniform, normal=normal,
-                      labels=labels, want_predictions=want_predictions)
+                      labels=labels, want_predictions=want_predictions,
+                      self_conditioning=self_supervised)          # module switch, as in the reference (:21, :110)
     gid = torch.from_numpy(graph_inputs.batch.var_graph_id.astype(np.int64)).to(out["solved"].device)
     var_correct = out["solved"].to(torch.float32)[gid]            # :176-180
     res = (out["solved_fraction"], out["assignment"], var_correct)

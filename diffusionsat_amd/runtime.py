@@ -136,7 +136,7 @@ class Session:
 
     def sample(self, n_steps: int = 32, rounds: int = 32, seed: int = 0, early_exit: bool = True,
                uniform=None, normal=None, labels=None, want_predictions: bool = False,
-               want_solved_fraction: bool = True):
+               want_solved_fraction: bool = True, self_conditioning: bool = False):
         lib = _lib.load()
         n, g = self.graph.n_vars, self.graph.n_graphs
         dev = self.device
@@ -144,7 +144,8 @@ class Session:
         solved = torch.empty(g, dtype=torch.uint8, device=dev)
         preds = torch.empty(n_steps, n, dtype=torch.float32, device=dev) if want_predictions else None
         frac = C.c_float(-1.0)
-        _lib.check(lib.dsat_sample(
+        fn = lib.dsat_sample_self if self_conditioning else lib.dsat_sample
+        _lib.check(fn(
             self.handle, int(n_steps), int(rounds), int(seed), int(bool(early_exit)),
             _ptr(uniform, torch.float32, n_steps * n, "uniform"),
             _ptr(normal, torch.float32, n_steps * rounds * n * 4, "normal"),

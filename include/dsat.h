@@ -164,6 +164,15 @@ int dsat_sample(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed,
                 const int32_t* labels, uint8_t* assignment_out, uint8_t* solved_out,
                 float* prediction_steps_out, float* solved_fraction_out, void* stream);
 
+/* diffusion() with the reference's `self_supervised` switch on
+ * (satuniformity/DiffusionSampler.py:21, :110-113): step t >= 1 runs diffusion_step_self with
+ * sigmoid(prediction) of step t-1 as denoised_num; step 0 has no previous prediction (:93).
+ * Arguments as dsat_sample. */
+int dsat_sample_self(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed, int32_t early_exit,
+                     const float* uniform, const float* normal, const int32_t* labels,
+                     uint8_t* assignment_out, uint8_t* solved_out, float* prediction_steps_out,
+                     float* solved_fraction_out, void* stream);
+
 /* ---- single operators (parity tests and per-kernel roofline measurements) --------
  * The layers the kernels sit behind, exposed one at a time.  All pointers dev. */
 

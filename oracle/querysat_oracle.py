@@ -404,7 +404,7 @@ def assignment_to_int(bits):
 
 
 def diffusion(weights, data, n_steps, normal, labels, uniform, rounds=32, early_exit=True,
-              dt=np.float32, trace=False):
+              dt=np.float32, trace=False, self_supervised=False):
     """satuniformity/DiffusionSampler.py:78-191 (baseline sampling, not self-supervised).
 
     ``normal`` [T, R, N, 4], ``labels`` [T, N], ``uniform`` [T, N, 1].
@@ -423,8 +423,9 @@ def diffusion(weights, data, n_steps, normal, labels, uniform, rounds=32, early_
         noise_scale = f(1 - t / n_steps)                         # :106
         x_noisy = randomized_rounding(x, np.asarray(uniform[t]))  # :107
         x = x_noisy                                              # :108-109 (use_baseline_sampling)
+        den = predictions[:, None] if (self_supervised and predictions is not None) else None   # :110-113, :58
         out = diffusion_step(weights, data, noise_scale, x_noisy, normal[t], labels[t], rounds,
-                             early_exit=early_exit, dt=dt)       # :115-117 -> :40-63
+                             early_exit=early_exit, dt=dt, denoised_num=den)   # :115-117 -> :40-63
         logits = out["prediction"]
         predictions = sigmoid(logits)                            # :61
         total_accuracy = sat_accuracy(logits, data)              # :119-124

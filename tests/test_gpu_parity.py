@@ -190,7 +190,7 @@ def test_early_exit_and_is_batch_sat(rt):
 
 
 @pytest.mark.parametrize("kind", ["3sat", "ragged"])
-def test_sample_matches_oracle_diffusion(rt, kind):
+def test_sample_matches_oracle_diffusion(rt, kind, self_cond=False):
     """dsat_sample vs diffusion() (satuniformity/DiffusionSampler.py:78-191), T=6 steps of
     R=8 rounds with all noise injected; compared step by step on the prediction logits while
     the discrete trajectory (randomized rounding) agrees, which the margins make robust."""
@@ -199,18 +199,33 @@ def test_sample_matches_oracle_diffusion(rt, kind):
     T, R = 6, 8
     d = draws(batch.n_vars, R, steps=T, seed=21)
     acc, final, steps = O.diffusion(ws, data, T, d["normal"], d["labels"], d["uniform"], rounds=R, early_exit=True,
-                                    dt=np.float32, trace=True)
+                                    dt=np.float32, trace=True, self_supervised=self_cond)
     s = _session(rt, batch, ws, max_rounds=R)
     for graph_replay in (False, True):
         s.set_graph_replay(graph_replay)
         out = s.sample(T, R, seed=0, early_exit=True, uniform=_dev(d["uniform"].reshape(T, -1)),
-                       normal=_dev(d["normal"]), labels=_dev(d["labels"]), want_predictions=True)
+                       normal=_dev(d["normal"]), labels=_dev(d["labels"]), want_predictions=True,
+                       self_conditioning=self_cond)
         preds = out["predictions"].cpu().numpy()
         for t in range(T):
             # selected-map logits only where the oracle's map choice was clear-cut
             _close(preds[t], steps[t]["logits"], 0, 5e-4)
         assert np.array_equal(out["assignment"].cpu().numpy().astype(np.float32), final.astype(np.float32))
         assert abs(out["solved_fraction"] - acc) < 1e-6
+
+
+def test_sample_self_conditioned_matches_oracle(rt):
+    """The sampler with the reference's `self_supervised` switch (DiffusionSampler.py:21, :110-113):
+    step t >= 1 is diffusion_step_self on sigmoid(prediction) of step t-1."""
+    test_sample_matches_oracle_diffusion(rt, "3sat", self_cond=True)
+    # and the switch changes the trajectory (the input is not ignored)
+    _, batch, data = make_all("3sat")
+    ws = oracle_weights(9)
+    d = draws(batch.n_vars, 8, steps=6, seed=21)
+    a = O.diffusion(ws, data, 6, d["normal"], d["labels"], d["uniform"], rounds=8, trace=True)[2]
+    b = O.diffusion(ws, data, 6, d["normal"], d["labels"], d["uniform"], rounds=8, trace=True,
+                    self_supervised=True)[2]
+    assert np.abs(a[0]["logits"] - b[0]["logits"]).max() == 0 and np.abs(a[1]["logits"] - b[1]["logits"]).max() > 1e-3
 
 
 def test_device_rng_matches_philox_mirror(rt):
