@@ -40,6 +40,15 @@ __device__ __forceinline__ void gload_b128(f32x4& dst, unsigned voff, const floa
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 #endif
 }
+// tools/chain_probe.hip defines DSAT_PROBE to time-stamp the phases of a layer
+#ifndef DSAT_PROBE
+#define DSAT_PROBE(id)
+#endif
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for
+// vector-memory loads, so weight fragments requested before it stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_release(f32x4& first) {
 #ifdef DSAT_EXP_NOLOAD
@@ -87,10 +96,13 @@ __device__ __forceinline__ void ring_step(const float4 (&a)[RB], f32x4 (&slot)[T
 // is the same at every step); the remaining < PD blocks are already in the ring when the
 // main loop ends and are consumed by a peeled tail.  The A fragment of step s+1 is read
 // from LDS during step s.  The queue is drained before returning.
+// `sync_in`: the input tile is still being written by other waves (previous layer's epilogue);
+// the workgroup barrier that publishes it is taken here, AFTER the ring has been primed, so
+// the first weight fragments travel while the waves wait for each other.
 template <int RB, int TPW>
 __device__ __forceinline__ void stream_gemm(const float* __restrict__ sIn, int ldin, int kblocks,
                                             const float4* __restrict__ wp, int t0, int ntiles, int lane,
-                                            f32x4 (&acc)[RB][TPW]) {
+                                            f32x4 (&acc)[RB][TPW], bool sync_in = false) {
     constexpr int PD = PrefetchDepth<TPW>::value;
     static_assert((PD - 1) * TPW <= 63, "vmcnt field is 6 bits");
     unsigned voff[TPW];
@@ -108,6 +120,7 @@ __device__ __forceinline__ void stream_gemm(const float* __restrict__ sIn, int l
 #pragma unroll
         for (int j = 0; j < TPW; ++j) gload_b128(breg[p][j], voff[j], wp + (size_t)kb * 64);
     }
+    if (sync_in) lds_barrier();
     float4 a_next[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -119,6 +132,7 @@ __device__ __forceinline__ void stream_gemm(const float* __restrict__ sIn, int l
     }
     const int main_blocks = kblocks / PD * PD;
     int kb = 0;
+    DSAT_PROBE(4);
     for (; kb < main_blocks; kb += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
@@ -150,6 +164,7 @@ __device__ __forceinline__ void stream_gemm(const float* __restrict__ sIn, int l
         }
     }
     // tail: blocks main_blocks .. kblocks-1 sit in slots 0 .. rem-1; nothing more is requested
+    DSAT_PROBE(5);
     wait_vmcnt_release<0>(breg[0][0]);
 #pragma unroll
     for (int p = 0; p < PD; ++p)
@@ -182,10 +197,15 @@ __device__ __forceinline__ void stream_gemm(const float* __restrict__ sIn, int l
 template <int RB, int TPW, int NWAVES, typename Store>
 __device__ __forceinline__ void dense_layer_tpw(const float* __restrict__ sIn, int ldin, int kblocks,
                                                 const float4* __restrict__ wp, const float* __restrict__ bias,
-                                                int ntiles, int act, int wave, int lane, Store&& store) {
+                                                int ntiles, int act, int wave, int lane, Store&& store,
+                                                bool sync_in) {
     for (int base = 0; base < ntiles; base += NWAVES * TPW) {
         const int t0 = base + wave * TPW;
-        if (t0 >= ntiles) continue;
+        const bool sync_now = sync_in && base == 0;   // every wave takes the barrier exactly once
+        if (t0 >= ntiles) {
+            if (sync_now) lds_barrier();
+            continue;
+        }
         f32x4 acc[RB][TPW];
         float bv[TPW];   // requested before the k-loop: a load in the epilogue would expose its latency
 #pragma unroll
@@ -197,7 +217,9 @@ __device__ __forceinline__ void dense_layer_tpw(const float* __restrict__ sIn, i
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int j = 0; j < TPW; ++j) acc[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        stream_gemm<RB, TPW>(sIn, ldin, kblocks, wp, t0, ntiles, lane, acc);
+        DSAT_PROBE(0);
+        stream_gemm<RB, TPW>(sIn, ldin, kblocks, wp, t0, ntiles, lane, acc, sync_now);
+        DSAT_PROBE(1);
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
             if (t0 + j < ntiles) {
@@ -219,19 +241,20 @@ __device__ __forceinline__ void dense_layer_tpw(const float* __restrict__ sIn, i
 template <int RB, int NWAVES, typename Store>
 __device__ __forceinline__ void dense_layer(const float* __restrict__ sIn, int ldin, int kblocks,
                                             const float4* __restrict__ wp, const float* __restrict__ bias,
-                                            int ntiles, int tpw, int act, int wave, int lane, Store&& store) {
+                                            int ntiles, int tpw, int act, int wave, int lane, Store&& store,
+                                            bool sync_in = false) {
     // register budget: RB * TPW accumulators of 4 VGPRs + PD * TPW weight fragments in flight
     constexpr int MAXT = RB == 1 ? 8 : RB == 2 ? 4 : 2;
     if constexpr (MAXT >= 8) {
-        if (tpw == 8) { dense_layer_tpw<RB, 8, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store); return; }
-        if (tpw == 6) { dense_layer_tpw<RB, 6, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store); return; }
+        if (tpw == 8) { dense_layer_tpw<RB, 8, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store, sync_in); return; }
+        if (tpw == 6) { dense_layer_tpw<RB, 6, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store, sync_in); return; }
     }
     if constexpr (MAXT >= 4) {
-        if (tpw == 4) { dense_layer_tpw<RB, 4, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store); return; }
-        if (tpw == 3) { dense_layer_tpw<RB, 3, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store); return; }
+        if (tpw == 4) { dense_layer_tpw<RB, 4, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store, sync_in); return; }
+        if (tpw == 3) { dense_layer_tpw<RB, 3, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store, sync_in); return; }
     }
-    if (tpw == 2) { dense_layer_tpw<RB, 2, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store); return; }
-    dense_layer_tpw<RB, 1, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store);
+    if (tpw == 2) { dense_layer_tpw<RB, 2, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store, sync_in); return; }
+    dense_layer_tpw<RB, 1, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store, sync_in);
 }
 
 inline int max_tpw_for_rb(int rb) { return rb == 1 ? 8 : rb == 2 ? 4 : 2; }

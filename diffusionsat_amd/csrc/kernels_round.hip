@@ -210,19 +210,22 @@ __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, 
     int ld_in = ldin;
     for (int l = 0; l < m.nlayers; ++l) {
         const ChainLayer& L = m.L[l];
+        // the barrier that publishes layer l-1's output is taken inside layer l, after its
+        // first weight fragments have been requested (fused_common.h, stream_gemm sync_in)
+        const bool sync_in = l > 0;
         if (l + 1 < m.nlayers) {
             float* o = (l & 1) ? bufB : bufA;
             const int ldo = (l & 1) ? ldB : ldA;
             dense_layer<RB, ROUND_NWAVES>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
-                                          [=](int row, int col, float v) { o[row * ldo + col] = v; });
+                                          [=](int row, int col, float v) { o[row * ldo + col] = v; }, sync_in);
             in = o;
             ld_in = ldo;
         } else {
             dense_layer<RB, ROUND_NWAVES>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 0, wave, lane,
-                                          final_store);
+                                          final_store, sync_in);
         }
-        __syncthreads();
     }
+    __syncthreads();
 }
 
 // Two independent 2-layer chains side by side: waves [0, NW/2) run chain A, the others chain B
@@ -238,16 +241,14 @@ __device__ __forceinline__ void run_chain_pair(const ChainSpec& ma, const float*
     if (wv < H) {                                          // weight base must stay in SGPRs
         dense_layer<1, H>(sInA, ldinA, ma.L[0].kblocks, ma.L[0].wp, ma.L[0].bias, ma.L[0].ntiles, ma.L[0].tpw_half, 1,
                           wv, lane, [=](int row, int col, float v) { bufA[row * ldA + col] = v; });
-        __syncthreads();
         dense_layer<1, H>(bufA, ldA, ma.L[1].kblocks, ma.L[1].wp, ma.L[1].bias, ma.L[1].ntiles, ma.L[1].tpw_half, 0,
-                          wv, lane, storeA);
+                          wv, lane, storeA, true);
         __syncthreads();
     } else {
         dense_layer<1, H>(sInB, ldinB, mb.L[0].kblocks, mb.L[0].wp, mb.L[0].bias, mb.L[0].ntiles, mb.L[0].tpw_half, 1,
                           wv - H, lane, [=](int row, int col, float v) { bufB[row * ldB + col] = v; });
-        __syncthreads();
         dense_layer<1, H>(bufB, ldB, mb.L[1].kblocks, mb.L[1].wp, mb.L[1].bias, mb.L[1].ntiles, mb.L[1].tpw_half, 0,
-                          wv - H, lane, storeB);
+                          wv - H, lane, storeB, true);
         __syncthreads();
     }
 }
