@@ -539,6 +539,25 @@ static ChainSpec make_chain(const std::vector<PackedLayer>& layers, int rb) {
         c.L[l].tpw = pick_tpw(c.L[l].ntiles, ROUND_NWAVES, max_tpw_for_rb(rb));
         c.L[l].tpw_half = pick_tpw(c.L[l].ntiles, ROUND_NWAVES / 2, max_tpw_for_rb(rb));
     }
+    // compile-time blockings (single pass per layer): see chain_static in fused_common.h
+    auto matches = [&](bool half, std::initializer_list<int> tp) {
+        if ((int)tp.size() != c.nlayers) return false;
+        const int nw = half ? ROUND_NWAVES / 2 : ROUND_NWAVES;
+        int l = 0;
+        for (int t : tp) {
+            const int have = half ? c.L[l].tpw_half : c.L[l].tpw;
+            if (have != t || c.L[l].ntiles > nw * t) return false;
+            ++l;
+        }
+        return true;
+    };
+    if (getenv("DSAT_NO_STATIC_CHAIN") == nullptr) {
+        if (rb == 1 && matches(false, {4, 4, 2})) c.static_id = CHAIN_442;
+        if (rb == 1 && matches(false, {2, 2, 1})) c.static_id = CHAIN_221;
+        if (rb == 4 && matches(false, {2, 2})) c.static_id = CHAIN_22;
+        if (rb == 1 && matches(true, {2, 1})) c.static_half_id = CHAIN_H21;
+        if (rb == 1 && matches(true, {3, 2})) c.static_half_id = CHAIN_H32;
+    }
     return c;
 }
 static int max_hidden_pad(const std::vector<PackedLayer>& layers) {

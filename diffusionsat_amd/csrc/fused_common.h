@@ -99,28 +99,36 @@ __device__ __forceinline__ void ring_step(const float4 (&a)[RB], f32x4 (&slot)[T
 // `sync_in`: the input tile is still being written by other waves (previous layer's epilogue);
 // the workgroup barrier that publishes it is taken here, AFTER the ring has been primed, so
 // the first weight fragments travel while the waves wait for each other.
-template <int RB, int TPW>
-__device__ __forceinline__ void stream_gemm(const float* __restrict__ sIn, int ldin, int kblocks,
-                                            const float4* __restrict__ wp, int t0, int ntiles, int lane,
-                                            f32x4 (&acc)[RB][TPW], bool sync_in = false) {
+template <int TPW>
+__device__ __forceinline__ void ring_prime(f32x4 (&breg)[PrefetchDepth<TPW>::value][TPW], unsigned (&voff)[TPW],
+                                           const float4* __restrict__ wp, int kblocks, int t0, int ntiles,
+                                           int lane) {
     constexpr int PD = PrefetchDepth<TPW>::value;
     static_assert((PD - 1) * TPW <= 63, "vmcnt field is 6 bits");
-    unsigned voff[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         const int t = (t0 + j < ntiles) ? t0 + j : ntiles - 1;
         voff[j] = (unsigned)((t * kblocks * 64 + lane) * 16);
     }
-    const float* pa = sIn + (lane & 15) * ldin + 4 * (lane >> 4);
     const int last = kblocks - 1;
-    f32x4 breg[PD][TPW];
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
         const int kb = p < last ? p : last;
 #pragma unroll
         for (int j = 0; j < TPW; ++j) gload_b128(breg[p][j], voff[j], wp + (size_t)kb * 64);
     }
-    if (sync_in) lds_barrier();
+}
+
+// The k-loop over a ring that ring_prime has filled.  Other vector-memory operations may be
+// outstanding, older or younger than the ring's: they only make the counted waits stricter.
+template <int RB, int TPW>
+__device__ __forceinline__ void gemm_primed(const float* __restrict__ sIn, int ldin, int kblocks,
+                                            const float4* __restrict__ wp,
+                                            f32x4 (&breg)[PrefetchDepth<TPW>::value][TPW], const unsigned (&voff)[TPW],
+                                            int lane, f32x4 (&acc)[RB][TPW]) {
+    constexpr int PD = PrefetchDepth<TPW>::value;
+    const float* pa = sIn + (lane & 15) * ldin + 4 * (lane >> 4);
+    const int last = kblocks - 1;
     float4 a_next[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -192,6 +200,47 @@ __device__ __forceinline__ void stream_gemm(const float* __restrict__ sIn, int l
     }
 }
 
+template <int RB, int TPW>
+__device__ __forceinline__ void stream_gemm(const float* __restrict__ sIn, int ldin, int kblocks,
+                                            const float4* __restrict__ wp, int t0, int ntiles, int lane,
+                                            f32x4 (&acc)[RB][TPW], bool sync_in = false) {
+    constexpr int PD = PrefetchDepth<TPW>::value;
+    unsigned voff[TPW];
+    f32x4 breg[PD][TPW];
+    ring_prime<TPW>(breg, voff, wp, kblocks, t0, ntiles, lane);
+    if (sync_in) lds_barrier();
+    gemm_primed<RB, TPW>(sIn, ldin, kblocks, wp, breg, voff, lane, acc);
+}
+
+template <int TPW>
+__device__ __forceinline__ void load_bias(float (&bv)[TPW], const float* __restrict__ bias, int t0, int ntiles,
+                                          int lane) {
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = t0 + j < ntiles ? t0 + j : ntiles - 1;
+        bv[j] = bias[t * 16 + (lane & 15)];
+    }
+}
+
+template <int RB, int TPW, typename Store>
+__device__ __forceinline__ void layer_epilogue(const f32x4 (&acc)[RB][TPW], const float (&bv)[TPW], int t0,
+                                               int ntiles, int act, int lane, Store&& store) {
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        if (t0 + j < ntiles) {
+            const int col = (t0 + j) * 16 + (lane & 15);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[rb][j][i] + bv[j];
+                    if (act) v = v > 0.f ? v : 0.2f * v;
+                    store(rb * 16 + 4 * (lane >> 4) + i, col, v);
+                }
+        }
+    }
+}
+
 // One Dense layer for the whole workgroup.  `store(row, col, value)` receives every output
 // element (row in [0,16*RB), col in [0, 16*ntiles)) after bias and activation.
 template <int RB, int TPW, int NWAVES, typename Store>
@@ -208,11 +257,7 @@ __device__ __forceinline__ void dense_layer_tpw(const float* __restrict__ sIn, i
         }
         f32x4 acc[RB][TPW];
         float bv[TPW];   // requested before the k-loop: a load in the epilogue would expose its latency
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-            const int t = t0 + j < ntiles ? t0 + j : ntiles - 1;
-            bv[j] = bias[t * 16 + (lane & 15)];
-        }
+        load_bias<TPW>(bv, bias, t0, ntiles, lane);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -220,20 +265,7 @@ __device__ __forceinline__ void dense_layer_tpw(const float* __restrict__ sIn, i
         DSAT_PROBE(0);
         stream_gemm<RB, TPW>(sIn, ldin, kblocks, wp, t0, ntiles, lane, acc, sync_now);
         DSAT_PROBE(1);
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-            if (t0 + j < ntiles) {
-                const int col = (t0 + j) * 16 + (lane & 15);
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = acc[rb][j][i] + bv[j];
-                        if (act) v = v > 0.f ? v : 0.2f * v;
-                        store(rb * 16 + 4 * (lane >> 4) + i, col, v);
-                    }
-            }
-        }
+        layer_epilogue<RB, TPW>(acc, bv, t0, ntiles, act, lane, store);
     }
 }
 
@@ -255,6 +287,75 @@ __device__ __forceinline__ void dense_layer(const float* __restrict__ sIn, int l
     }
     if (tpw == 2) { dense_layer_tpw<RB, 2, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store, sync_in); return; }
     dense_layer_tpw<RB, 1, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store, sync_in);
+}
+
+// A whole 2- or 3-layer chain with the register blocking of every layer fixed at compile time
+// (T2 == 0: two layers).  Knowing the next layer's blocking lets the code request its first
+// PD k-blocks of weights BEFORE the current layer's epilogue and barrier, so the per-layer
+// fixed cost (L2 latency of the ring prime, ~1-1.5k cycles, plus epilogue and barrier skew)
+// overlaps instead of adding up.  Requires a single pass per layer (ntiles <= NW * T).
+// Layer l reads in_l (sIn, bufA, bufB) and hidden layers write bufA, then bufB.
+struct StaticLayer { const float4* wp; const float* bias; int kblocks, ntiles; };
+
+template <int RB, int NW, int T0, int T1, int T2, typename Store>
+__device__ __forceinline__ void chain_static(const StaticLayer& L0, const StaticLayer& L1, const StaticLayer& L2,
+                                             const float* sIn, int ldin, float* bufA, int ldA, float* bufB,
+                                             int ldB, int wv /* wave-uniform (SGPR) */, int lane,
+                                             Store&& final_store, bool sync_in) {
+    constexpr int TL = T2 > 0 ? T2 : 1;
+    const int t0 = wv * T0, t1 = wv * T1, t2 = wv * TL;
+    const bool on0 = t0 < L0.ntiles, on1 = t1 < L1.ntiles, on2 = T2 > 0 && t2 < L2.ntiles;
+    float bv0[T0], bv1[T1], bv2[TL];
+    if (on0) load_bias<T0>(bv0, L0.bias, t0, L0.ntiles, lane);
+    if (on1) load_bias<T1>(bv1, L1.bias, t1, L1.ntiles, lane);
+    if (on2) load_bias<TL>(bv2, L2.bias, t2, L2.ntiles, lane);
+    // ---- layer 0
+    f32x4 acc0[RB][T0];
+    unsigned vo0[T0];
+    f32x4 r0[PrefetchDepth<T0>::value][T0];
+    if (on0) ring_prime<T0>(r0, vo0, L0.wp, L0.kblocks, t0, L0.ntiles, lane);
+    if (sync_in) lds_barrier();
+    if (on0) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < T0; ++j) acc0[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_primed<RB, T0>(sIn, ldin, L0.kblocks, L0.wp, r0, vo0, lane, acc0);
+    }
+    // ---- layer 1: ring requested before layer 0's epilogue and the barrier
+    f32x4 acc1[RB][T1];
+    unsigned vo1[T1];
+    f32x4 r1[PrefetchDepth<T1>::value][T1];
+    if (on1) ring_prime<T1>(r1, vo1, L1.wp, L1.kblocks, t1, L1.ntiles, lane);
+    if (on0) layer_epilogue<RB, T0>(acc0, bv0, t0, L0.ntiles, 1, lane,
+                                    [=](int row, int col, float v) { bufA[row * ldA + col] = v; });
+    lds_barrier();
+    if (on1) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < T1; ++j) acc1[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_primed<RB, T1>(bufA, ldA, L1.kblocks, L1.wp, r1, vo1, lane, acc1);
+    }
+    if constexpr (T2 > 0) {
+        f32x4 acc2[RB][TL];
+        unsigned vo2[TL];
+        f32x4 r2[PrefetchDepth<TL>::value][TL];
+        if (on2) ring_prime<TL>(r2, vo2, L2.wp, L2.kblocks, t2, L2.ntiles, lane);
+        if (on1) layer_epilogue<RB, T1>(acc1, bv1, t1, L1.ntiles, 1, lane,
+                                        [=](int row, int col, float v) { bufB[row * ldB + col] = v; });
+        lds_barrier();
+        if (on2) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int j = 0; j < TL; ++j) acc2[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_primed<RB, TL>(bufB, ldB, L2.kblocks, L2.wp, r2, vo2, lane, acc2);
+            layer_epilogue<RB, TL>(acc2, bv2, t2, L2.ntiles, 0, lane, final_store);
+        }
+    } else {
+        if (on1) layer_epilogue<RB, T1>(acc1, bv1, t1, L1.ntiles, 0, lane, final_store);
+    }
 }
 
 inline int max_tpw_for_rb(int rb) { return rb == 1 ? 8 : rb == 2 ? 4 : 2; }

@@ -206,6 +206,22 @@ __device__ __forceinline__ void tile_colsums(int tile_lo, int rows, const TileMe
 template <int RB, typename Store>
 __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, int ldin, float* bufA, int ldA,
                                           float* bufB, int ldB, int wave, int lane, Store&& final_store) {
+    if (m.static_id != CHAIN_GENERIC) {   // blocking known at compile time: cross-layer weight prefetch
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const StaticLayer S0{m.L[0].wp, m.L[0].bias, m.L[0].kblocks, m.L[0].ntiles};
+        const StaticLayer S1{m.L[1].wp, m.L[1].bias, m.L[1].kblocks, m.L[1].ntiles};
+        const StaticLayer S2{m.L[2].wp, m.L[2].bias, m.L[2].kblocks, m.L[2].ntiles};
+        if constexpr (RB == 1) {
+            if (m.static_id == CHAIN_442)
+                chain_static<1, ROUND_NWAVES, 4, 4, 2>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, false);
+            else
+                chain_static<1, ROUND_NWAVES, 2, 2, 1>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, false);
+        } else if constexpr (RB == 4) {
+            chain_static<4, ROUND_NWAVES, 2, 2, 0>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, false);
+        }
+        __syncthreads();
+        return;
+    }
     const float* in = sIn;
     int ld_in = ldin;
     for (int l = 0; l < m.nlayers; ++l) {
@@ -238,6 +254,20 @@ __device__ __forceinline__ void run_chain_pair(const ChainSpec& ma, const float*
                                                int wave, int lane, StoreA&& storeA, StoreB&& storeB) {
     constexpr int H = ROUND_NWAVES / 2;
     const int wv = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform for the compiler: the
+    if (ma.static_half_id == CHAIN_H21 && mb.static_half_id == CHAIN_H32) {
+        const StaticLayer none{nullptr, nullptr, 0, 0};
+        if (wv < H) {
+            const StaticLayer S0{ma.L[0].wp, ma.L[0].bias, ma.L[0].kblocks, ma.L[0].ntiles};
+            const StaticLayer S1{ma.L[1].wp, ma.L[1].bias, ma.L[1].kblocks, ma.L[1].ntiles};
+            chain_static<1, H, 2, 1, 0>(S0, S1, none, sInA, ldinA, bufA, ldA, nullptr, 0, wv, lane, storeA, false);
+        } else {
+            const StaticLayer S0{mb.L[0].wp, mb.L[0].bias, mb.L[0].kblocks, mb.L[0].ntiles};
+            const StaticLayer S1{mb.L[1].wp, mb.L[1].bias, mb.L[1].kblocks, mb.L[1].ntiles};
+            chain_static<1, H, 3, 2, 0>(S0, S1, none, sInB, ldinB, bufB, ldB, nullptr, 0, wv - H, lane, storeB, false);
+        }
+        __syncthreads();
+        return;
+    }
     if (wv < H) {                                          // weight base must stay in SGPRs
         dense_layer<1, H>(sInA, ldinA, ma.L[0].kblocks, ma.L[0].wp, ma.L[0].bias, ma.L[0].ntiles, ma.L[0].tpw_half, 1,
                           wv, lane, [=](int row, int col, float v) { bufA[row * ldA + col] = v; });
