@@ -535,7 +535,9 @@ static ChainSpec make_chain(const std::vector<PackedLayer>& layers, int rb) {
         c.L[l].wp = reinterpret_cast<const float4*>(layers[l].wp);
         c.L[l].bias = layers[l].bias;
         c.L[l].kblocks = layers[l].kblocks();
-        c.L[l].ntiles = layers[l].ntiles();
+        // column tiles that hold real outputs (npad is rounded to 32 for the per-layer GEMM path;
+        // the fragment-ordered weights are tile-major, so trailing all-padding tiles are just not visited)
+        c.L[l].ntiles = (layers[l].out_dim + 15) / 16;
         c.L[l].tpw = pick_tpw(c.L[l].ntiles, ROUND_NWAVES, max_tpw_for_rb(rb));
         c.L[l].tpw_half = pick_tpw(c.L[l].ntiles, ROUND_NWAVES / 2, max_tpw_for_rb(rb));
     }
@@ -554,9 +556,19 @@ static ChainSpec make_chain(const std::vector<PackedLayer>& layers, int rb) {
     if (getenv("DSAT_NO_STATIC_CHAIN") == nullptr) {
         if (rb == 1 && matches(false, {4, 4, 2})) c.static_id = CHAIN_442;
         if (rb == 1 && matches(false, {2, 2, 1})) c.static_id = CHAIN_221;
-        if (rb == 4 && matches(false, {2, 2})) c.static_id = CHAIN_22;
+        if (rb == 4 && matches(false, {2, 2})) {
+            c.static_id = CHAIN_22;
+            // 13 column tiles on 8 waves: balanced (tile, row block) split, see chain_static MIX0
+            if (c.L[0].ntiles == 3 * ROUND_NWAVES / 2 + 1 && getenv("DSAT_NO_MIX") == nullptr) c.static_id = CHAIN_22M;
+        }
         if (rb == 1 && matches(true, {2, 1})) c.static_half_id = CHAIN_H21;
         if (rb == 1 && matches(true, {3, 2})) c.static_half_id = CHAIN_H32;
+    }
+    if (getenv("DSAT_DEBUG_PLAN") != nullptr) {
+        fprintf(stderr, "[dsat] chain rb=%d layers=%d static=%d half=%d :", rb, c.nlayers, c.static_id, c.static_half_id);
+        for (int l = 0; l < c.nlayers; ++l)
+            fprintf(stderr, " (kb=%d nt=%d tpw=%d/%d)", c.L[l].kblocks, c.L[l].ntiles, c.L[l].tpw, c.L[l].tpw_half);
+        fprintf(stderr, "\n");
     }
     return c;
 }

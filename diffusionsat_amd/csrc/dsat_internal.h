@@ -160,7 +160,7 @@ hipError_t launch_chain(const ChainArgs& a, int rb, int nwaves, hipStream_t st);
 //   P3 var tile   : clause->literal gather (R4, R11), update_gate chain (R12), column sums
 // static_id / static_half_id: which compile-time blocking of fused_common.h's chain_static the
 // chain matches when all NW (resp. NW/2) waves run it; 0 = none (generic per-layer path).
-enum { CHAIN_GENERIC = 0, CHAIN_442 = 1, CHAIN_221 = 2, CHAIN_22 = 3, CHAIN_H21 = 4, CHAIN_H32 = 5 };
+enum { CHAIN_GENERIC = 0, CHAIN_442 = 1, CHAIN_221 = 2, CHAIN_22 = 3, CHAIN_H21 = 4, CHAIN_H32 = 5, CHAIN_22M = 6 };
 struct ChainSpec { ChainLayer L[4]; int nlayers; int static_id, static_half_id; };
 struct RoundArgs {
     // graph

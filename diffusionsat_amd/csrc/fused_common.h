@@ -58,6 +58,13 @@ __device__ __forceinline__ void wait_vmcnt_release(f32x4& first) {
 #endif
 }
 __device__ __forceinline__ void release(f32x4& r) { asm volatile("" : "+v"(r)); }
+// Make the compiler complete (wait for) an ordinary load HERE: its own s_waitcnt counts only
+// the loads it knows, so a wait placed after asm loads were issued would drain those as well.
+template <int N>
+__device__ __forceinline__ void pin_values(float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
 
 // One k-block step of the ring: consume slot `p` (MFMAs in tile pairs), then refill it from
 // `sb` when REFILL.  Tiles are processed in pairs: 4 k-steps x 2 tiles x RB row blocks of
@@ -65,20 +72,28 @@ __device__ __forceinline__ void release(f32x4& r) { asm volatile("" : "+v"(r)); 
 // the old fragment, so a ring slot keeps its physical registers and no copy of an in-flight
 // register can appear.  sched_barrier pins the interleave: one pair of 1-KiB loads per
 // 8*RB MFMAs instead of a burst of TPW loads at the end of the k-block.
-template <int RB, int TPW, bool REFILL>
-__device__ __forceinline__ void ring_step(const float4 (&a)[RB], f32x4 (&slot)[TPW], const unsigned (&voff)[TPW],
-                                          const float4* sb, f32x4 (&acc)[RB][TPW]) {
+// PART: the last tile of the wave is a partial one -- only one of its RB row blocks belongs to
+// this wave (A fragment `asp`, accumulator acc[0][TPW-1]); see chain_static's MIX0.
+template <int RB, int TPW, bool REFILL, bool PART = false>
+__device__ __forceinline__ void ring_step(const float4 (&a)[RB], const float4& asp, f32x4 (&slot)[TPW],
+                                          const unsigned (&voff)[TPW], const float4* sb, f32x4 (&acc)[RB][TPW]) {
 #pragma unroll
     for (int jp = 0; jp < TPW; jp += 2) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int j = jp; j < jp + 2 && j < TPW; ++j)
+            for (int j = jp; j < jp + 2 && j < TPW; ++j) {
+                if (PART && j == TPW - 1) {
+                    const float av = kk == 0 ? asp.x : kk == 1 ? asp.y : kk == 2 ? asp.z : asp.w;
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, slot[j][kk], acc[0][j], 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    const float av = kk == 0 ? a[rb].x : kk == 1 ? a[rb].y : kk == 2 ? a[rb].z : a[rb].w;
-                    acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, slot[j][kk], acc[rb][j], 0, 0, 0);
+                    for (int rb = 0; rb < RB; ++rb) {
+                        const float av = kk == 0 ? a[rb].x : kk == 1 ? a[rb].y : kk == 2 ? a[rb].z : a[rb].w;
+                        acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, slot[j][kk], acc[rb][j], 0, 0, 0);
+                    }
                 }
+            }
         if (REFILL) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -100,16 +115,13 @@ __device__ __forceinline__ void ring_step(const float4 (&a)[RB], f32x4 (&slot)[T
 // the workgroup barrier that publishes it is taken here, AFTER the ring has been primed, so
 // the first weight fragments travel while the waves wait for each other.
 template <int TPW>
-__device__ __forceinline__ void ring_prime(f32x4 (&breg)[PrefetchDepth<TPW>::value][TPW], unsigned (&voff)[TPW],
-                                           const float4* __restrict__ wp, int kblocks, int t0, int ntiles,
-                                           int lane) {
+__device__ __forceinline__ void ring_prime_tiles(f32x4 (&breg)[PrefetchDepth<TPW>::value][TPW], unsigned (&voff)[TPW],
+                                                 const float4* __restrict__ wp, int kblocks,
+                                                 const int (&tiles)[TPW], int lane) {
     constexpr int PD = PrefetchDepth<TPW>::value;
     static_assert((PD - 1) * TPW <= 63, "vmcnt field is 6 bits");
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-        const int t = (t0 + j < ntiles) ? t0 + j : ntiles - 1;
-        voff[j] = (unsigned)((t * kblocks * 64 + lane) * 16);
-    }
+    for (int j = 0; j < TPW; ++j) voff[j] = (unsigned)((tiles[j] * kblocks * 64 + lane) * 16);
     const int last = kblocks - 1;
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
@@ -119,16 +131,29 @@ __device__ __forceinline__ void ring_prime(f32x4 (&breg)[PrefetchDepth<TPW>::val
     }
 }
 
+template <int TPW>
+__device__ __forceinline__ void ring_prime(f32x4 (&breg)[PrefetchDepth<TPW>::value][TPW], unsigned (&voff)[TPW],
+                                           const float4* __restrict__ wp, int kblocks, int t0, int ntiles,
+                                           int lane) {
+    int tiles[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) tiles[j] = (t0 + j < ntiles) ? t0 + j : ntiles - 1;
+    ring_prime_tiles<TPW>(breg, voff, wp, kblocks, tiles, lane);
+}
+
 // The k-loop over a ring that ring_prime has filled.  Other vector-memory operations may be
 // outstanding, older or younger than the ring's: they only make the counted waits stricter.
-template <int RB, int TPW>
+template <int RB, int TPW, bool PART = false>
 __device__ __forceinline__ void gemm_primed(const float* __restrict__ sIn, int ldin, int kblocks,
                                             const float4* __restrict__ wp,
                                             f32x4 (&breg)[PrefetchDepth<TPW>::value][TPW], const unsigned (&voff)[TPW],
-                                            int lane, f32x4 (&acc)[RB][TPW]) {
+                                            int lane, f32x4 (&acc)[RB][TPW], int sp_rb = 0) {
     constexpr int PD = PrefetchDepth<TPW>::value;
     const float* pa = sIn + (lane & 15) * ldin + 4 * (lane >> 4);
+    const float* pasp = pa + sp_rb * 16 * ldin;   // PART: the row block of the partial tile
     const int last = kblocks - 1;
+    float4 asp_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PART) asp_next = *reinterpret_cast<const float4*>(pasp);
     float4 a_next[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -147,9 +172,11 @@ __device__ __forceinline__ void gemm_primed(const float* __restrict__ sIn, int l
             float4 a[RB];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) a[rb] = a_next[rb];
+            const float4 asp = asp_next;
             {   // A fragment of the next step (address clamped to the last k-block)
                 const int k1 = kb + p + 1;
                 const int kc = k1 < last ? k1 : last;
+                if (PART) asp_next = *reinterpret_cast<const float4*>(pasp + kc * 16);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
 #ifdef DSAT_EXP_NOLDS
@@ -168,7 +195,7 @@ __device__ __forceinline__ void gemm_primed(const float* __restrict__ sIn, int l
 #else
             const int kn = kb + p + PD < last ? kb + p + PD : last;
 #endif
-            ring_step<RB, TPW, true>(a, breg[p], voff, wp + (size_t)kn * 64, acc);
+            ring_step<RB, TPW, true, PART>(a, asp, breg[p], voff, wp + (size_t)kn * 64, acc);
         }
     }
     // tail: blocks main_blocks .. kblocks-1 sit in slots 0 .. rem-1; nothing more is requested
@@ -185,8 +212,10 @@ __device__ __forceinline__ void gemm_primed(const float* __restrict__ sIn, int l
             float4 a[RB];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) a[rb] = a_next[rb];
+            const float4 asp = asp_next;
             const int k1 = main_blocks + p + 1;
             const int kc = k1 < last ? k1 : last;
+            if (PART) asp_next = *reinterpret_cast<const float4*>(pasp + kc * 16);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
 #ifdef DSAT_EXP_NOLDS
@@ -195,7 +224,7 @@ __device__ __forceinline__ void gemm_primed(const float* __restrict__ sIn, int l
                 a_next[rb] = *reinterpret_cast<const float4*>(pa + rb * 16 * ldin + kc * 16);
 #endif
             }
-            ring_step<RB, TPW, false>(a, breg[p], voff, wp, acc);
+            ring_step<RB, TPW, false, PART>(a, asp, breg[p], voff, wp, acc);
         }
     }
 }
@@ -297,39 +326,91 @@ __device__ __forceinline__ void dense_layer(const float* __restrict__ sIn, int l
 // Layer l reads in_l (sIn, bufA, bufB) and hidden layers write bufA, then bufB.
 struct StaticLayer { const float4* wp; const float* bias; int kblocks, ntiles; };
 
-template <int RB, int NW, int T0, int T1, int T2, typename Store>
+// MIX0 (layer 0 has 3*NW/2 + 1 column tiles, T0 == 2, RB == NW/2): waves [0, NW/2) own two
+// whole tiles; wave NW/2 + i owns tile NW + i and row block i of the last tile.  Waves w and
+// w + NW/2 share a SIMD, so every SIMD gets 3*RB + 1 (tile, row block) units instead of the
+// 4*RB that "two tiles per wave, last wave idle" puts on the busiest one.
+template <int RB, int NW, int T0, int T1, int T2, bool MIX0 = false, typename Store>
 __device__ __forceinline__ void chain_static(const StaticLayer& L0, const StaticLayer& L1, const StaticLayer& L2,
                                              const float* sIn, int ldin, float* bufA, int ldA, float* bufB,
                                              int ldB, int wv /* wave-uniform (SGPR) */, int lane,
                                              Store&& final_store, bool sync_in) {
+    static_assert(!MIX0 || (T0 == 2 && RB == NW / 2), "MIX0 layout");
     constexpr int TL = T2 > 0 ? T2 : 1;
     const int t0 = wv * T0, t1 = wv * T1, t2 = wv * TL;
-    const bool on0 = t0 < L0.ntiles, on1 = t1 < L1.ntiles, on2 = T2 > 0 && t2 < L2.ntiles;
+    const bool mixed = MIX0 && wv >= NW / 2;
+    const bool on0 = MIX0 || t0 < L0.ntiles, on1 = t1 < L1.ntiles, on2 = T2 > 0 && t2 < L2.ntiles;
+    int tiles0[T0];
+#pragma unroll
+    for (int j = 0; j < T0; ++j) tiles0[j] = t0 + j < L0.ntiles ? t0 + j : L0.ntiles - 1;
+    if (mixed) { tiles0[0] = NW + (wv - NW / 2); tiles0[T0 - 1] = 3 * NW / 2; }
+    const int sp_rb = mixed ? wv - NW / 2 : 0;
     float bv0[T0], bv1[T1], bv2[TL];
-    if (on0) load_bias<T0>(bv0, L0.bias, t0, L0.ntiles, lane);
-    if (on1) load_bias<T1>(bv1, L1.bias, t1, L1.ntiles, lane);
-    if (on2) load_bias<TL>(bv2, L2.bias, t2, L2.ntiles, lane);
-    // ---- layer 0
-    f32x4 acc0[RB][T0];
-    unsigned vo0[T0];
-    f32x4 r0[PrefetchDepth<T0>::value][T0];
-    if (on0) ring_prime<T0>(r0, vo0, L0.wp, L0.kblocks, t0, L0.ntiles, lane);
-    if (sync_in) lds_barrier();
     if (on0) {
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int j = 0; j < T0; ++j) acc0[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_primed<RB, T0>(sIn, ldin, L0.kblocks, L0.wp, r0, vo0, lane, acc0);
+        for (int j = 0; j < T0; ++j) bv0[j] = L0.bias[tiles0[j] * 16 + (lane & 15)];
     }
+    if (on1) load_bias<T1>(bv1, L1.bias, t1, L1.ntiles, lane);
+    if (on2) load_bias<TL>(bv2, L2.bias, t2, L2.ntiles, lane);
+    // ---- layer 0 (the two layouts are separate code paths from the ring prime on: a ring
+    // shared between two differently allocated loops would be copied while still in flight)
+    DSAT_PROBE(0);
+    f32x4 acc0[RB][T0];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int j = 0; j < T0; ++j) acc0[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (MIX0 && mixed) {
+        unsigned vo0[T0];
+        f32x4 r0[PrefetchDepth<T0>::value][T0];
+        ring_prime_tiles<T0>(r0, vo0, L0.wp, L0.kblocks, tiles0, lane);
+        if (sync_in) lds_barrier();
+        gemm_primed<RB, T0, MIX0>(sIn, ldin, L0.kblocks, L0.wp, r0, vo0, lane, acc0, sp_rb);
+    } else if (on0) {
+        unsigned vo0[T0];
+        f32x4 r0[PrefetchDepth<T0>::value][T0];
+        ring_prime_tiles<T0>(r0, vo0, L0.wp, L0.kblocks, tiles0, lane);
+        if (sync_in) lds_barrier();
+        gemm_primed<RB, T0>(sIn, ldin, L0.kblocks, L0.wp, r0, vo0, lane, acc0);
+    } else if (sync_in) {
+        lds_barrier();
+    }
+    DSAT_PROBE(1);
+    // biases were requested before layer 0; the queue is empty here (the k-loop drained it)
+    if (on0) pin_values(bv0);
+    if (on1) pin_values(bv1);
+    if (on2) pin_values(bv2);
     // ---- layer 1: ring requested before layer 0's epilogue and the barrier
     f32x4 acc1[RB][T1];
     unsigned vo1[T1];
     f32x4 r1[PrefetchDepth<T1>::value][T1];
     if (on1) ring_prime<T1>(r1, vo1, L1.wp, L1.kblocks, t1, L1.ntiles, lane);
-    if (on0) layer_epilogue<RB, T0>(acc0, bv0, t0, L0.ntiles, 1, lane,
-                                    [=](int row, int col, float v) { bufA[row * ldA + col] = v; });
+    if (on0) {
+        auto store0 = [=](int row, int col, float v) { bufA[row * ldA + col] = v; };
+        if (mixed) {   // tile 0 whole, last tile: row block sp_rb only (its accumulator is acc0[0][T0-1])
+#pragma unroll
+            for (int j = 0; j < T0; ++j) {
+                const int col = tiles0[j] * 16 + (lane & 15);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    if (j == T0 - 1 && rb > 0) break;
+                    const int rbo = j == T0 - 1 ? sp_rb : rb;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc0[rb][j][i] + bv0[j];
+                        v = v > 0.f ? v : 0.2f * v;
+                        store0(rbo * 16 + 4 * (lane >> 4) + i, col, v);
+                    }
+                }
+            }
+        } else {
+            layer_epilogue<RB, T0>(acc0, bv0, t0, L0.ntiles, 1, lane, store0);
+        }
+    }
+    DSAT_PROBE(2);
     lds_barrier();
+    DSAT_PROBE(3);
+    DSAT_PROBE(0);
     if (on1) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -337,6 +418,7 @@ __device__ __forceinline__ void chain_static(const StaticLayer& L0, const Static
             for (int j = 0; j < T1; ++j) acc1[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         gemm_primed<RB, T1>(bufA, ldA, L1.kblocks, L1.wp, r1, vo1, lane, acc1);
     }
+    DSAT_PROBE(1);
     if constexpr (T2 > 0) {
         f32x4 acc2[RB][TL];
         unsigned vo2[TL];
@@ -344,13 +426,17 @@ __device__ __forceinline__ void chain_static(const StaticLayer& L0, const Static
         if (on2) ring_prime<TL>(r2, vo2, L2.wp, L2.kblocks, t2, L2.ntiles, lane);
         if (on1) layer_epilogue<RB, T1>(acc1, bv1, t1, L1.ntiles, 1, lane,
                                         [=](int row, int col, float v) { bufB[row * ldB + col] = v; });
+        DSAT_PROBE(2);
         lds_barrier();
+        DSAT_PROBE(3);
+        DSAT_PROBE(0);
         if (on2) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int j = 0; j < TL; ++j) acc2[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             gemm_primed<RB, TL>(bufB, ldB, L2.kblocks, L2.wp, r2, vo2, lane, acc2);
+            DSAT_PROBE(1);
             layer_epilogue<RB, TL>(acc2, bv2, t2, L2.ntiles, 0, lane, final_store);
         }
     } else {

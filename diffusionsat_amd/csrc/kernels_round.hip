@@ -217,7 +217,10 @@ __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, 
             else
                 chain_static<1, ROUND_NWAVES, 2, 2, 1>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, false);
         } else if constexpr (RB == 4) {
-            chain_static<4, ROUND_NWAVES, 2, 2, 0>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, false);
+            if (m.static_id == CHAIN_22M)
+                chain_static<4, ROUND_NWAVES, 2, 2, 0, true>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, false);
+            else
+                chain_static<4, ROUND_NWAVES, 2, 2, 0>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, false);
         }
         __syncthreads();
         return;

@@ -23,11 +23,11 @@ extern __shared__ long long s_probe_dyn[];            // [8 waves][64 records] (
 using namespace dsat;
 
 struct Layer { const float4* wp; const float* bias; int kblocks, ntiles, tpw; };
-struct Args { Layer L[4]; int nlayers; int ld0, ld1; float* y; long long* probe; };
+struct Args { Layer L[4]; int nlayers; int ld0, ld1; float* y; long long* probe; int mix; };
 
 template <int RB>
 __global__ __launch_bounds__(512) void kern(Args a) {
-    __shared__ __attribute__((aligned(16))) float smem[36000];
+    __shared__ __attribute__((aligned(16))) float smem[39000];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     constexpr int BM = 16 * RB;
     float* in = smem;
@@ -36,6 +36,27 @@ __global__ __launch_bounds__(512) void kern(Args a) {
     for (int i = tid; i < BM * a.ld0; i += 512) in[i] = (float)(i % 13) * 0.01f;
     __syncthreads();
     int ld_in = a.ld0, ld_out = a.ld1;
+#ifdef STATIC_CHAIN
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const StaticLayer S0{a.L[0].wp, a.L[0].bias, a.L[0].kblocks, a.L[0].ntiles};
+        const StaticLayer S1{a.L[1].wp, a.L[1].bias, a.L[1].kblocks, a.L[1].ntiles};
+        const StaticLayer S2{a.L[2].wp, a.L[2].bias, a.L[2].kblocks, a.L[2].ntiles};
+        float* y = a.y;
+        auto fin = [=](int row, int col, float v) { y[((size_t)blockIdx.x * BM + row) * 256 + (col & 255)] = v; };
+        float* bufB = out + BM * a.ld1;
+        if constexpr (RB == 4) {
+            if (a.mix) chain_static<4, 8, 2, 2, 0, true>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
+            else chain_static<4, 8, 2, 2, 0>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
+        } else if constexpr (RB == 1) {
+            if (a.L[0].tpw == 4) chain_static<1, 8, 4, 4, 2>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
+            else chain_static<1, 8, 2, 2, 1>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
+        }
+        DSAT_PROBE(2);
+        __syncthreads();
+        DSAT_PROBE(3);
+    }
+#else
     for (int l = 0; l < a.nlayers; ++l) {
         const Layer& L = a.L[l];
         float* o = out;
@@ -54,8 +75,9 @@ __global__ __launch_bounds__(512) void kern(Args a) {
         float* t = in; in = out; out = t;
         const int tl = ld_in; ld_in = ld_out; ld_out = tl;
     }
+#endif
     __syncthreads();
-    if (tid < 64) a.y[blockIdx.x * 64 + tid] = in[tid];
+    if (tid < 64 && blockIdx.x == 0) a.y[tid] += in[tid];
     __syncthreads();
     for (int i = tid; i < 8 * PROBE_SLOTS; i += 512) a.probe[(size_t)blockIdx.x * 8 * PROBE_SLOTS + i] = s_probe_dyn[i];
 }
@@ -69,8 +91,18 @@ int main(int argc, char** argv) {
     Args a{};
     a.nlayers = (int)dims.size() - 1;
     int maxw = 0;
-    for (int d : dims) maxw = std::max(maxw, (d + 15) / 16 * 16);
-    a.ld0 = a.ld1 = maxw + 8;
+#ifdef STATIC_CHAIN
+    for (size_t i = 1; i + 1 < dims.size(); ++i) maxw = std::max(maxw, (dims[i] + 15) / 16 * 16);
+#else
+    for (size_t i = 1; i < dims.size(); ++i) maxw = std::max(maxw, (dims[i] + 15) / 16 * 16);
+#endif
+    a.ld0 = (dims[0] + 15) / 16 * 16 + 8;
+    a.ld1 = maxw + 8;
+    {
+        const int bm = 16 * rb;
+        const int need = bm * (a.ld0 + a.ld1 * (a.nlayers > 2 ? 2 : 1));
+        if (need > 39000) { printf("LDS plan %d floats does not fit\n", need); return 1; }
+    }
     for (int l = 0; l < a.nlayers; ++l) {
         const int kb = (dims[l] + 15) / 16, nt = (dims[l + 1] + 15) / 16;
         std::vector<float> w((size_t)nt * kb * 256), b(nt * 16, 0.01f);
@@ -81,7 +113,8 @@ int main(int argc, char** argv) {
         (void)hipMemcpy(bias, b.data(), b.size() * 4, hipMemcpyHostToDevice);
         a.L[l] = Layer{wp, bias, kb, nt, pick_tpw(nt, 8, max_tpw_for_rb(rb))};
     }
-    (void)hipMalloc(&a.y, blocks * 64 * 4);
+    (void)hipMalloc(&a.y, ((size_t)blocks * 16 * rb * 256 + 128) * 4);
+    a.mix = getenv("MIX") != nullptr;
     long long* probe;
     const size_t np = (size_t)blocks * 8 * PROBE_SLOTS;
     (void)hipMalloc(&probe, np * 8);
