@@ -61,9 +61,9 @@ __device__ __forceinline__ void release(f32x4& r) { asm volatile("" : "+v"(r)); 
 // Make the compiler complete (wait for) an ordinary load HERE: its own s_waitcnt counts only
 // the loads it knows, so a wait placed after asm loads were issued would drain those as well.
 template <int N>
-__device__ __forceinline__ void pin_values(float (&v)[N]) {
+__device__ __forceinline__ void pin_values(float4 (&v)[N]) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
 }
 
 // One k-block step of the ring: consume slot `p` (MFMAs in tile pairs), then refill it from
@@ -72,6 +72,10 @@ __device__ __forceinline__ void pin_values(float (&v)[N]) {
 // the old fragment, so a ring slot keeps its physical registers and no copy of an in-flight
 // register can appear.  sched_barrier pins the interleave: one pair of 1-KiB loads per
 // 8*RB MFMAs instead of a burst of TPW loads at the end of the k-block.
+// The weight fragment is the MFMA's A operand and the activation fragment its B operand, i.e.
+// the instruction computes the TRANSPOSED output tile: lane l ends up with output columns
+// 16*t + 4*(l>>4) .. +3 of row (l & 15) -- four consecutive columns of one row, so the epilogue
+// writes 16-byte vectors (LDS and HBM) instead of four strided scalars.
 // PART: the last tile of the wave is a partial one -- only one of its RB row blocks belongs to
 // this wave (A fragment `asp`, accumulator acc[0][TPW-1]); see chain_static's MIX0.
 template <int RB, int TPW, bool REFILL, bool PART = false>
@@ -85,12 +89,12 @@ __device__ __forceinline__ void ring_step(const float4 (&a)[RB], const float4& a
             for (int j = jp; j < jp + 2 && j < TPW; ++j) {
                 if (PART && j == TPW - 1) {
                     const float av = kk == 0 ? asp.x : kk == 1 ? asp.y : kk == 2 ? asp.z : asp.w;
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, slot[j][kk], acc[0][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(slot[j][kk], av, acc[0][j], 0, 0, 0);
                 } else {
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) {
                         const float av = kk == 0 ? a[rb].x : kk == 1 ? a[rb].y : kk == 2 ? a[rb].z : a[rb].w;
-                        acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, slot[j][kk], acc[rb][j], 0, 0, 0);
+                        acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(slot[j][kk], av, acc[rb][j], 0, 0, 0);
                     }
                 }
             }
@@ -242,36 +246,40 @@ __device__ __forceinline__ void stream_gemm(const float* __restrict__ sIn, int l
 }
 
 template <int TPW>
-__device__ __forceinline__ void load_bias(float (&bv)[TPW], const float* __restrict__ bias, int t0, int ntiles,
+__device__ __forceinline__ void load_bias(float4 (&bv)[TPW], const float* __restrict__ bias, int t0, int ntiles,
                                           int lane) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         const int t = t0 + j < ntiles ? t0 + j : ntiles - 1;
-        bv[j] = bias[t * 16 + (lane & 15)];
+        bv[j] = *reinterpret_cast<const float4*>(bias + t * 16 + 4 * (lane >> 4));
     }
 }
 
+__device__ __forceinline__ float4 bias_act(const f32x4& acc, const float4& b, int act) {
+    float4 v = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
+    if (act) {   // leaky_relu(0.2): max(v, 0.2 v)
+        v.x = fmaxf(v.x, 0.2f * v.x); v.y = fmaxf(v.y, 0.2f * v.y);
+        v.z = fmaxf(v.z, 0.2f * v.z); v.w = fmaxf(v.w, 0.2f * v.w);
+    }
+    return v;
+}
+
+// `store(row, col, v)` receives the four outputs (row, col .. col+3); col is a multiple of 4.
 template <int RB, int TPW, typename Store>
-__device__ __forceinline__ void layer_epilogue(const f32x4 (&acc)[RB][TPW], const float (&bv)[TPW], int t0,
+__device__ __forceinline__ void layer_epilogue(const f32x4 (&acc)[RB][TPW], const float4 (&bv)[TPW], int t0,
                                                int ntiles, int act, int lane, Store&& store) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         if (t0 + j < ntiles) {
-            const int col = (t0 + j) * 16 + (lane & 15);
+            const int col = (t0 + j) * 16 + 4 * (lane >> 4);
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = acc[rb][j][i] + bv[j];
-                    if (act) v = v > 0.f ? v : 0.2f * v;
-                    store(rb * 16 + 4 * (lane >> 4) + i, col, v);
-                }
+            for (int rb = 0; rb < RB; ++rb) store(rb * 16 + (lane & 15), col, bias_act(acc[rb][j], bv[j], act));
         }
     }
 }
 
-// One Dense layer for the whole workgroup.  `store(row, col, value)` receives every output
-// element (row in [0,16*RB), col in [0, 16*ntiles)) after bias and activation.
+// One Dense layer for the whole workgroup.  `store(row, col, float4)` receives every output
+// (row in [0,16*RB), columns col..col+3 in [0, 16*ntiles)) after bias and activation.
 template <int RB, int TPW, int NWAVES, typename Store>
 __device__ __forceinline__ void dense_layer_tpw(const float* __restrict__ sIn, int ldin, int kblocks,
                                                 const float4* __restrict__ wp, const float* __restrict__ bias,
@@ -285,7 +293,7 @@ __device__ __forceinline__ void dense_layer_tpw(const float* __restrict__ sIn, i
             continue;
         }
         f32x4 acc[RB][TPW];
-        float bv[TPW];   // requested before the k-loop: a load in the epilogue would expose its latency
+        float4 bv[TPW];   // requested before the k-loop: a load in the epilogue would expose its latency
         load_bias<TPW>(bv, bias, t0, ntiles, lane);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -345,10 +353,11 @@ __device__ __forceinline__ void chain_static(const StaticLayer& L0, const Static
     for (int j = 0; j < T0; ++j) tiles0[j] = t0 + j < L0.ntiles ? t0 + j : L0.ntiles - 1;
     if (mixed) { tiles0[0] = NW + (wv - NW / 2); tiles0[T0 - 1] = 3 * NW / 2; }
     const int sp_rb = mixed ? wv - NW / 2 : 0;
-    float bv0[T0], bv1[T1], bv2[TL];
+    float4 bv0[T0], bv1[T1], bv2[TL];
     if (on0) {
 #pragma unroll
-        for (int j = 0; j < T0; ++j) bv0[j] = L0.bias[tiles0[j] * 16 + (lane & 15)];
+        for (int j = 0; j < T0; ++j)
+            bv0[j] = *reinterpret_cast<const float4*>(L0.bias + tiles0[j] * 16 + 4 * (lane >> 4));
     }
     if (on1) load_bias<T1>(bv1, L1.bias, t1, L1.ntiles, lane);
     if (on2) load_bias<TL>(bv2, L2.bias, t2, L2.ntiles, lane);
@@ -386,21 +395,16 @@ __device__ __forceinline__ void chain_static(const StaticLayer& L0, const Static
     f32x4 r1[PrefetchDepth<T1>::value][T1];
     if (on1) ring_prime<T1>(r1, vo1, L1.wp, L1.kblocks, t1, L1.ntiles, lane);
     if (on0) {
-        auto store0 = [=](int row, int col, float v) { bufA[row * ldA + col] = v; };
+        auto store0 = [=](int row, int col, float4 v) { *reinterpret_cast<float4*>(bufA + row * ldA + col) = v; };
         if (mixed) {   // tile 0 whole, last tile: row block sp_rb only (its accumulator is acc0[0][T0-1])
 #pragma unroll
             for (int j = 0; j < T0; ++j) {
-                const int col = tiles0[j] * 16 + (lane & 15);
+                const int col = tiles0[j] * 16 + 4 * (lane >> 4);
+                if (j == T0 - 1) {
+                    store0(sp_rb * 16 + (lane & 15), col, bias_act(acc0[0][j], bv0[j], 1));
+                } else {
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    if (j == T0 - 1 && rb > 0) break;
-                    const int rbo = j == T0 - 1 ? sp_rb : rb;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = acc0[rb][j][i] + bv0[j];
-                        v = v > 0.f ? v : 0.2f * v;
-                        store0(rbo * 16 + 4 * (lane >> 4) + i, col, v);
-                    }
+                    for (int rb = 0; rb < RB; ++rb) store0(rb * 16 + (lane & 15), col, bias_act(acc0[rb][j], bv0[j], 1));
                 }
             }
         } else {
@@ -425,7 +429,7 @@ __device__ __forceinline__ void chain_static(const StaticLayer& L0, const Static
         f32x4 r2[PrefetchDepth<TL>::value][TL];
         if (on2) ring_prime<TL>(r2, vo2, L2.wp, L2.kblocks, t2, L2.ntiles, lane);
         if (on1) layer_epilogue<RB, T1>(acc1, bv1, t1, L1.ntiles, 1, lane,
-                                        [=](int row, int col, float v) { bufB[row * ldB + col] = v; });
+                                        [=](int row, int col, float4 v) { *reinterpret_cast<float4*>(bufB + row * ldB + col) = v; });
         DSAT_PROBE(2);
         lds_barrier();
         DSAT_PROBE(3);

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(NWAVES * 64) void chain_kernel(ChainArgs a) {
             float* o = out;
             const int ld = ld_out;
             dense_layer<RB, NWAVES>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
-                                    [=](int row, int col, float v) { o[row * ld + col] = v; });
+                                    [=](int row, int col, float4 v) { *reinterpret_cast<float4*>(o + row * ld + col) = v; });
             __syncthreads();
             float* t = in; in = out; out = t;
             const int tl = ld_in; ld_in = ld_out; ld_out = tl;
@@ -46,8 +46,13 @@ __global__ __launch_bounds__(NWAVES * 64) void chain_kernel(ChainArgs a) {
             float* y = a.y;
             const int ldy = a.ldy, ncols = a.ncols_y, rows = a.rows;
             dense_layer<RB, NWAVES>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 0, wave, lane,
-                                    [=](int row, int col, float v) {
-                                        if (r0 + row < rows && col < ncols) y[(size_t)(r0 + row) * ldy + col] = v;
+                                    [=](int row, int col, float4 v) {   // ncols / ldy are arbitrary: scalar stores
+                                        if (r0 + row >= rows) return;
+                                        float* yr = y + (size_t)(r0 + row) * ldy;
+                                        if (col < ncols) yr[col] = v.x;
+                                        if (col + 1 < ncols) yr[col + 1] = v.y;
+                                        if (col + 2 < ncols) yr[col + 2] = v.z;
+                                        if (col + 3 < ncols) yr[col + 3] = v.w;
                                     });
         }
     }

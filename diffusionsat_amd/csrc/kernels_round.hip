@@ -236,7 +236,7 @@ __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, 
             float* o = (l & 1) ? bufB : bufA;
             const int ldo = (l & 1) ? ldB : ldA;
             dense_layer<RB, ROUND_NWAVES>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
-                                          [=](int row, int col, float v) { o[row * ldo + col] = v; }, sync_in);
+                                          [=](int row, int col, float4 v) { st4(o + row * ldo + col, v); }, sync_in);
             in = o;
             ld_in = ldo;
         } else {
@@ -273,13 +273,13 @@ __device__ __forceinline__ void run_chain_pair(const ChainSpec& ma, const float*
     }
     if (wv < H) {                                          // weight base must stay in SGPRs
         dense_layer<1, H>(sInA, ldinA, ma.L[0].kblocks, ma.L[0].wp, ma.L[0].bias, ma.L[0].ntiles, ma.L[0].tpw_half, 1,
-                          wv, lane, [=](int row, int col, float v) { bufA[row * ldA + col] = v; });
+                          wv, lane, [=](int row, int col, float4 v) { st4(bufA + row * ldA + col, v); });
         dense_layer<1, H>(bufA, ldA, ma.L[1].kblocks, ma.L[1].wp, ma.L[1].bias, ma.L[1].ntiles, ma.L[1].tpw_half, 0,
                           wv, lane, storeA, true);
         __syncthreads();
     } else {
         dense_layer<1, H>(sInB, ldinB, mb.L[0].kblocks, mb.L[0].wp, mb.L[0].bias, mb.L[0].ntiles, mb.L[0].tpw_half, 1,
-                          wv - H, lane, [=](int row, int col, float v) { bufB[row * ldB + col] = v; });
+                          wv - H, lane, [=](int row, int col, float4 v) { st4(bufB + row * ldB + col, v); });
         dense_layer<1, H>(bufB, ldB, mb.L[1].kblocks, mb.L[1].wp, mb.L[1].bias, mb.L[1].ntiles, mb.L[1].tpw_half, 0,
                           wv - H, lane, storeB, true);
         __syncthreads();
@@ -386,20 +386,22 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     float* q = a.q;
     float* sp = a.sp;
     // R14: logits of the previous round from the pre-mix state
-    auto store_logits = [=](int row, int col, float v) {
+    auto store_logits = [=](int row, int col, float4 v) {
         const int n = tile_lo + row;
         if (n < N && col < LOGIT_MAPS) {
-            lg[(size_t)n * LOGIT_MAPS + col] = v;
-            if (tr != nullptr) tr[(size_t)n * LOGIT_MAPS + col] = v;
+            st4(lg + (size_t)n * LOGIT_MAPS + col, v);
+            if (tr != nullptr) st4(tr + (size_t)n * LOGIT_MAPS + col, v);
         }
     };
     // R2: query = variables_query(v1); softplus(+-query) feeds the clause gather (loss/sat.py:132-133)
-    auto store_query = [=](int row, int col, float v) {
+    auto store_query = [=](int row, int col, float4 v) {
         const int n = tile_lo + row;
         if (n < N && col < F) {
-            q[(size_t)n * F + col] = v;
-            sp[(size_t)n * F + col] = softplus_f(v);
-            sp[(size_t)(N + n) * F + col] = softplus_f(-v);
+            st4(q + (size_t)n * F + col, v);
+            st4(sp + (size_t)n * F + col,
+                make_float4(softplus_f(v.x), softplus_f(v.y), softplus_f(v.z), softplus_f(v.w)));
+            st4(sp + (size_t)(N + n) * F + col,
+                make_float4(softplus_f(-v.x), softplus_f(-v.y), softplus_f(-v.z), softplus_f(-v.w)));
         }
     };
     if (a.round > 0 && !a.tail && a.mout.nlayers == 2 && a.mq.nlayers == 2) {
@@ -415,9 +417,9 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     DSAT_STAMP(a, 3);
     {   // R6: literals = [lit_mlp(v1)[:, :128] ; [:, 128:]]
         float* lits = a.lits;
-        run_chain<1>(a.mlit, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float v) {
+        run_chain<1>(a.mlit, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float4 v) {
             const int n = tile_lo + row;
-            if (n < N && col < 2 * F) lits[((size_t)(col < F ? n : N + n)) * F + (col & (F - 1))] = v;
+            if (n < N && col < 2 * F) st4(lits + ((size_t)(col < F ? n : N + n)) * F + (col & (F - 1)), v);
         });
     }
     DSAT_STAMP(a, 4);
@@ -544,13 +546,13 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
         float* ncv = a.ncv;
         float* stage = sX;   // the input tile is dead once layer 0 has run
         const int lds = F + 8;
-        run_chain<RB>(a.mcl, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float v) {
+        run_chain<RB>(a.mcl, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float4 v) {
             const int c = tile_lo + row;
             if (col < F) {
-                if (c < C) vla[(size_t)c * F + col] = v;
+                if (c < C) st4(vla + (size_t)c * F + col, v);
             } else if (col < 2 * F) {
-                stage[row * lds + (col - F)] = v;
-                if (c < C) ncv[(size_t)c * F + (col - F)] = v;
+                st4(stage + row * lds + (col - F), v);
+                if (c < C) st4(ncv + (size_t)c * F + (col - F), v);
             }
         });
         DSAT_STAMP(a, 3);
@@ -688,11 +690,11 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
         float* newv = a.newv;
         float* stage = sX;
         const int lds = F + 8;
-        run_chain<1>(a.mupd, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float v) {
+        run_chain<1>(a.mupd, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float4 v) {
             const int n = tile_lo + row;
             if (col < F) {
-                stage[row * lds + col] = v;
-                if (n < N) newv[(size_t)n * F + col] = v;
+                st4(stage + row * lds + col, v);
+                if (n < N) st4(newv + (size_t)n * F + col, v);
             }
         });
         DSAT_STAMP(a, 2);

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(512) void kern(Args a) {
         const StaticLayer S1{a.L[1].wp, a.L[1].bias, a.L[1].kblocks, a.L[1].ntiles};
         const StaticLayer S2{a.L[2].wp, a.L[2].bias, a.L[2].kblocks, a.L[2].ntiles};
         float* y = a.y;
-        auto fin = [=](int row, int col, float v) { y[((size_t)blockIdx.x * BM + row) * 256 + (col & 255)] = v; };
+        auto fin = [=](int row, int col, float4 v) { *reinterpret_cast<float4*>(y + ((size_t)blockIdx.x * BM + row) * 256 + (col & 255)) = v; };
         float* bufB = out + BM * a.ld1;
         if constexpr (RB == 4) {
             if (a.mix) chain_static<4, 8, 2, 2, 0, true>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
@@ -63,11 +63,11 @@ __global__ __launch_bounds__(512) void kern(Args a) {
         const int ld = ld_out;
 #ifdef SYNC_IN
         dense_layer<RB, 8>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
-                           [=](int row, int col, float v) { o[row * ld + col] = v; }, l > 0);
+                           [=](int row, int col, float4 v) { *reinterpret_cast<float4*>(o + row * ld + col) = v; }, l > 0);
         DSAT_PROBE(2);
 #else
         dense_layer<RB, 8>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
-                           [=](int row, int col, float v) { o[row * ld + col] = v; });
+                           [=](int row, int col, float4 v) { *reinterpret_cast<float4*>(o + row * ld + col) = v; });
         DSAT_PROBE(2);
         __syncthreads();
 #endif
