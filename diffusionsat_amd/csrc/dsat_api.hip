@@ -449,11 +449,13 @@ static void carve(dsat_session* s, Slab& sl) {
     const size_t N = g->N, C = std::max(g->C, 1), G = g->G, R = s->max_rounds;
     s->V = sl.take<float>(N * F); s->Vlog = sl.take<float>(N * F); s->Cs = sl.take<float>(C * F);
     s->q = sl.take<float>(N * F); s->hq = nullptr;
-    s->lits = sl.take<float>(2 * N * F); s->grad = sl.take<float>(N * F); s->vl = sl.take<float>(2 * N * F);
+    // lits / sp / closs4 / vla carry one extra all-zero row (index 2N resp. C) that the fused
+    // gathers read for list slots past a row's end (the slab is zeroed once, nothing writes there)
+    s->lits = sl.take<float>((2 * N + 1) * F); s->grad = sl.take<float>(N * F); s->vl = sl.take<float>(2 * N * F);
     s->newv = sl.take<float>(N * F); s->ho = nullptr;
     s->logits = sl.take<float>(N * LOGIT_MAPS); s->aux = sl.take<float>(R * N * AUX_W);
-    s->cmsg = sl.take<float>(C * F); s->closs4 = sl.take<float>(C * F);
-    s->vla = sl.take<float>(C * F); s->ncv = sl.take<float>(C * F);
+    s->cmsg = sl.take<float>(C * F); s->closs4 = sl.take<float>((C + 1) * F);
+    s->vla = sl.take<float>((C + 1) * F); s->ncv = sl.take<float>(C * F);
     for (int m = 0; m < DSAT_N_MLP; ++m) {
         const size_t rows = (m == DSAT_MLP_CLAUSE) ? C : N;
         s->hid_ld[m] = round_up(L.hidden[m], 32);
@@ -475,7 +477,7 @@ static void carve(dsat_session* s, Slab& sl) {
     for (int m = 0; m < DSAT_N_MLP; ++m) max_k = std::max<size_t>(max_k, s->w->mlp[m][0].kpad);
     s->scratch = sl.take<float>(std::max(N, C) * max_k);
     s->ctl = sl.take<Ctl>(1);
-    s->sp = sl.take<float>(2 * N * F);
+    s->sp = sl.take<float>((2 * N + 1) * F);
     s->psum_v = sl.take<float>(std::max<size_t>(s->h_vtile_seg.empty() ? 1 : s->h_vtile_seg.back(), 1) * F);
     s->psum_c = sl.take<float>(2 * std::max<size_t>(s->h_ctile_seg.empty() ? 1 : s->h_ctile_seg.back(), 1) * F);
     s->vmeta = sl.take<int32_t>(s->h_vmeta.size());
@@ -595,6 +597,7 @@ static bool plan_round(dsat_session* s) {
     a.V = s->V; a.Cs = s->Cs; a.q = s->q; a.sp = s->sp; a.lits = s->lits; a.closs4 = s->closs4;
     a.vla = s->vla; a.ncv = s->ncv; a.newv = s->newv; a.logits = s->logits;
     a.psum_v = s->psum_v; a.psum_c_rd = s->psum_c; a.psum_c_wr = s->psum_c; a.noisy = s->in_noisy; a.ctl = s->ctl;
+    a.aux = s->aux;
     const int LDS = 40960;
     bool ok = true;
     {   // P1: [X 16x152 | Vlog 16x136 | A | B | mean]
@@ -973,6 +976,8 @@ static void enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int 
     RoundArgs a1 = s->ra1, a2 = s->ra2, a3 = s->ra3;
     a1.check_done = a2.check_done = a3.check_done = early_exit;
     a1.trace_logits = trace_logits;
+    // the non-state columns of v1 (normal draw, noisy_num, noise_scale, denoised) of all rounds
+    L.run(KC_MISC, [&] { launch_aux(s->aux, s->g->N, rounds, s->in_noisy, s->ctl, st); });   // :214-219, :239
     for (int r = 0; r <= rounds; ++r) {
         a1.round = r;
         a1.tail = r == rounds;

@@ -176,6 +176,7 @@ struct RoundArgs {
     const float* psum_c_rd;
     float* psum_c_wr;
     const float* noisy;    // [N,2] noisy_num of this denoising step
+    const float* aux;      // [rounds,N,AUX_W] non-state columns of v1 for every round (aux_kernel, once per step)
     Ctl* ctl;
     float* trace_logits;   // optional [rounds,N,8]
     // select/SAT outputs (the S blocks appended to P2 and the stand-alone S kernel)

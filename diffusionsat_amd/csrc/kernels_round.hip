@@ -35,29 +35,27 @@ constexpr int LDS_FLOATS = 40960;   // 160 KiB static (see kernels_chain.hip on 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+// sigmoid(x) and sigmoid(-x) from one exponential: z = exp(-|x|) in (0,1], so nothing overflows
+__device__ __forceinline__ void sigmoid_pair(float x, float& s, float& sn) {
+    const float z = expf(-fabsf(x));
+    const float big = __builtin_amdgcn_rcpf(1.f + z), small = z * big;
+    s = x >= 0.f ? big : small;
+    sn = x >= 0.f ? small : big;
+}
 __device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
 
-// [normal(4) | noisy_num(2) | noise_scale | 0 ...] = the non-state columns of v1 (:214-219, :239)
-__device__ __forceinline__ void write_aux_row(float* dst, const Ctl* ctl, const float* noisy, int n, int N,
-                                              int round, bool valid) {
-    float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f, n0 = 0.f, n1 = 0.f, ns = 0.f, d0 = 0.f, d1 = 0.f;
+// [normal(4) | noisy_num(2) | noise_scale | denoised(2) | 0 ...] = the non-state columns of v1
+// (:214-219, :239).  aux_kernel writes them for every round once per denoising step (the
+// Philox + Box-Muller draw costs ~10^3 instructions, too many for a tile prologue that a
+// whole workgroup waits on); the tiles only copy their 64-byte rows.
+__device__ __forceinline__ void load_aux_row(float* dst, const float* __restrict__ aux, int n, int N, int round,
+                                             bool valid) {
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0, v3 = v0;
     if (valid) {
-        if (ctl->inj_normal != nullptr) {
-            const float4 v = ld4(ctl->inj_normal + ctl->normal_step_stride * ctl->step + ((size_t)round * N + n) * 4);
-            z0 = v.x; z1 = v.y; z2 = v.z; z3 = v.w;
-        } else {
-            u32x4 c = {(uint32_t)n, (uint32_t)round, ctl->step, (uint32_t)STREAM_NORMAL};
-            const u32x4 x = philox4x32_10(c, (uint32_t)ctl->seed, (uint32_t)(ctl->seed >> 32));
-            box_muller(x.x, x.y, z0, z1);
-            box_muller(x.z, x.w, z2, z3);
-        }
-        n0 = noisy[2 * n]; n1 = noisy[2 * n + 1]; ns = ctl->noise_scale;
-        if (ctl->denoised != nullptr && ctl->step >= ctl->denoised_from_step) { d0 = ctl->denoised[n]; d1 = 1.f - d0; }   // :218
+        const float* src = aux + ((size_t)round * N + n) * AUX_W;
+        v0 = ld4(src); v1 = ld4(src + 4); v2 = ld4(src + 8); v3 = ld4(src + 12);
     }
-    st4(dst, make_float4(z0, z1, z2, z3));
-    st4(dst + 4, make_float4(n0, n1, ns, d0));
-    st4(dst + 8, make_float4(d1, 0.f, 0.f, 0.f));
-    st4(dst + 12, make_float4(0.f, 0.f, 0.f, 0.f));
+    st4(dst, v0); st4(dst + 4, v1); st4(dst + 8, v2); st4(dst + 12, v3);
 }
 
 // Per-tile scalars precomputed on the host (one 64-B record, one load): removes the dependent
@@ -374,7 +372,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     const TileMetaDev tm = load_meta(a.vmeta, tile);
     if (tid < BM) {   // aux columns of v1 for this round (independent of everything else)
         const int n = tile_lo + tid;
-        write_aux_row(sX + tid * ldx + F, a.ctl, a.noisy, n, N, a.round, n < N && !a.tail);
+        load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N && !a.tail);
     }
     pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.newv, a.V, a.round == 0, sX, ldx, sVlog,
                       ldv, sMean, tid);
@@ -475,68 +473,72 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
                           nullptr, 0, sMean, tid);   // its barriers also publish sPtr / sIdx
     }
     DSAT_STAMP(a, 1);
-    // R3 + R5 + R7: half-wave hw owns rows hw, hw+16, ...; two rows are in flight at a time
+    // R3 + R5 + R7: half-wave hw owns rows hw, hw+16, ...; all its rows (ROWS <= 4) are in
+    // flight together, four literals each, so a 3-SAT tile needs one round trip to memory
     {
         const int sub = tid & 31, hw = tid >> 5;
+        constexpr int U = ROWS;
+        constexpr int GJ = 4;
+        float4 S[U], M[U];
+        int e0[U], e1[U];
+        int nmax = 0;
 #pragma unroll
-        for (int kp = 0; kp < ROWS; kp += 2) {
-            float4 S[2], M[2];
-            int e0[2], e1[2];
+        for (int u = 0; u < U; ++u) {
+            S[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            M[u] = S[u];
+            const int r = hw + u * (NT / 32);
+            e0[u] = 0; e1[u] = 0;
+            if (tile_lo + r < tile_hi) {
+                if (staged) { e0[u] = sPtr[r]; e1[u] = sPtr[r + 1]; }
+                else { e0[u] = a.c_rowptr[tile_lo + r]; e1[u] = a.c_rowptr[tile_lo + r + 1]; }
+            }
+            nmax = max(nmax, e1[u] - e0[u]);
+        }
+        const unsigned zrow = 2u * (unsigned)N;   // the all-zero row of sp / lits
+        for (int off = 0; off < nmax; off += GJ) {   // branch-free, see the P3 gather
+            unsigned l[U][GJ];
+            float4 sv[U][GJ], lv[U][GJ];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                S[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                M[u] = S[u];
-                const int r = hw + (kp + u) * (NT / 32);
-                e0[u] = 0; e1[u] = 0;
-                if (kp + u < ROWS && tile_lo + r < tile_hi) {
-                    if (staged) { e0[u] = sPtr[r]; e1[u] = sPtr[r + 1]; }
-                    else { e0[u] = a.c_rowptr[tile_lo + r]; e1[u] = a.c_rowptr[tile_lo + r + 1]; }
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < GJ; ++j) {
+                    const int e = e0[u] + off + j;
+                    const bool ok = e < e1[u];
+                    int idx;
+                    if (staged) idx = sIdx[e];
+                    else idx = ok ? a.c_lit[e] : 0;
+                    l[u][j] = ok ? (unsigned)idx : zrow;
                 }
-            }
-            const int nmax = max(e1[0] - e0[0], e1[1] - e0[1]);
-            for (int off = 0; off < nmax; off += 4) {
-                int l[2][4];
-                float4 sv[2][4], lv[2][4];
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int e = e0[u] + off + j;
-                        l[u][j] = e < e1[u] ? (staged ? sIdx[e] : a.c_lit[e]) : -1;
-                    }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (l[u][j] >= 0) {
-                            sv[u][j] = ld4(a.sp + (size_t)l[u][j] * F + sub * 4);
-                            lv[u][j] = ld4(a.lits + (size_t)l[u][j] * F + sub * 4);
-                        }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (l[u][j] >= 0) {
-                            S[u].x += sv[u][j].x; S[u].y += sv[u][j].y; S[u].z += sv[u][j].z; S[u].w += sv[u][j].w;
-                            M[u].x += lv[u][j].x; M[u].y += lv[u][j].y; M[u].z += lv[u][j].z; M[u].w += lv[u][j].w;
-                        }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (kp + u >= ROWS) continue;
-                const int r = hw + (kp + u) * (NT / 32);
-                const int c = tile_lo + r;
-                float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
-                float rw = 0.f;
-                if (c < C) {
-                    rw = a.rev_w[c];
-                    cl = make_float4(4.f * expf(-S[u].x), 4.f * expf(-S[u].y), 4.f * expf(-S[u].z),
-                                     4.f * expf(-S[u].w));
-                    st4(a.closs4 + (size_t)c * F + sub * 4, cl);
+                for (int j = 0; j < GJ; ++j) {
+                    const unsigned o = l[u][j] * (unsigned)F + (unsigned)sub * 4u;
+                    sv[u][j] = ld4(a.sp + o);
+                    lv[u][j] = ld4(a.lits + o);
                 }
-                st4(sX + r * ldx + F + sub * 4, make_float4(M[u].x * rw, M[u].y * rw, M[u].z * rw, M[u].w * rw));
-                st4(sX + r * ldx + 2 * F + sub * 4, cl);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < GJ; ++j) {
+                    S[u].x += sv[u][j].x; S[u].y += sv[u][j].y; S[u].z += sv[u][j].z; S[u].w += sv[u][j].w;
+                    M[u].x += lv[u][j].x; M[u].y += lv[u][j].y; M[u].z += lv[u][j].z; M[u].w += lv[u][j].w;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = hw + u * (NT / 32);
+            const int c = tile_lo + r;
+            float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
+            float rw = 0.f;
+            if (c < C) {
+                rw = a.rev_w[c];
+                cl = make_float4(4.f * expf(-S[u].x), 4.f * expf(-S[u].y), 4.f * expf(-S[u].z),
+                                 4.f * expf(-S[u].w));
+                st4(a.closs4 + (size_t)c * F + sub * 4, cl);
             }
+            st4(sX + r * ldx + F + sub * 4, make_float4(M[u].x * rw, M[u].y * rw, M[u].z * rw, M[u].w * rw));
+            st4(sX + r * ldx + 2 * F + sub * 4, cl);
         }
     }
     __syncthreads();
@@ -567,6 +569,7 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
     if (a.check_done && a.ctl->done != 0) return;
     constexpr int BM = ROUND_BM_VAR;
     constexpr int PASSES = BM / ROUND_NWAVES;   // variables per wave
+    constexpr int GJ = 8;                       // clause rows in flight per literal (x PASSES x 2 arrays)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.N;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -581,6 +584,7 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
     constexpr int OFF_V = F, OFF_AUX = 2 * F, OFF_POS = 2 * F + AUX_W, OFF_NEG = 3 * F + AUX_W;
     DSAT_STAMP(a, 0);
     const TileMetaDev tm = load_meta(a.vmeta, tile);
+    DSAT_STAMP(a, 4);
     {   // R4 + R11: one wave per variable, half 0 = literal +v, half 1 = literal -v
         const int sub = lane & 31, half = lane >> 5;
         // literal -> clause lists of the tile's +v rows and -v rows -> LDS (sA is free until layer 0)
@@ -594,24 +598,27 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
         const bool st1 = stage_csr(a.l_rowptr, a.l_clause, N + tile_lo, nrows, tm.e_base1, tm.e_end1, sPtr1, sIdx1, cap, tid);
         const bool staged = st0 && st1;
         // rows that do not depend on the lists: q (half 0) and the carried state (half 1)
-        float4 rowv[PASSES];
+        float4 rowv[PASSES], qrow[PASSES];
         float wdeg[PASSES], wv[PASSES];
 #pragma unroll
         for (int u = 0; u < PASSES; ++u) {
             const int v = tile_lo + wave + u * ROUND_NWAVES;
             rowv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            qrow[u] = rowv[u];
             wdeg[u] = 0.f; wv[u] = 0.f;
             if (v < N) {
-                rowv[u] = half == 0 ? ld4(a.q + (size_t)v * F + sub * 4) : ld4(a.V + (size_t)v * F + sub * 4);
+                qrow[u] = ld4(a.q + (size_t)v * F + sub * 4);
+                if (half == 1) rowv[u] = ld4(a.V + (size_t)v * F + sub * 4);
                 wdeg[u] = a.deg_w[v + half * N];
                 wv[u] = a.vdeg_w[v];
             }
         }
         if (tid < BM) {
             const int n = tile_lo + tid;
-            write_aux_row(sX + tid * ldx + OFF_AUX, a.ctl, a.noisy, n, N, a.round, n < N);
+            load_aux_row(sX + tid * ldx + OFF_AUX, a.aux, n, N, a.round, n < N);
         }
         __syncthreads();   // lists staged
+        DSAT_STAMP(a, 5);
         float4 M[PASSES], VL[PASSES];
         int e0[PASSES], e1[PASSES];
         int nmax = 0;
@@ -634,33 +641,44 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
         }
         nmax = max(nmax, __shfl_xor(nmax, 32));   // both halves run the same trip count
         const int* sIdx = half ? sIdx1 : sIdx0;
-        for (int off = 0; off < nmax; off += 4) {
-            int ci[PASSES][4];
-            float4 cv[PASSES][4], vv[PASSES][4];
+        // Branch-free: a conditional load would make the compiler wait for memory at every
+        // join, serialising the rows.  List slots past a row's end read the all-zero row C
+        // (dsat_api.hip carve), so nothing is masked; offsets are 32-bit (SGPR base + VGPR).
+        const unsigned zrow = (unsigned)a.C;
+        for (int off = 0; off < nmax; off += GJ) {
+            unsigned ci[PASSES][GJ];
+            float4 cv[PASSES][GJ], vv[PASSES][GJ];
 #pragma unroll
             for (int u = 0; u < PASSES; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < GJ; ++j) {
                     const int e = e0[u] + off + j;
-                    ci[u][j] = e < e1[u] ? (staged ? sIdx[e] : a.l_clause[e]) : -1;
+                    const bool ok = e < e1[u];
+                    int idx;
+                    if (staged) idx = sIdx[e];              // LDS: reading past the list is harmless
+                    else idx = ok ? a.l_clause[e] : 0;      // rare path (lists larger than the LDS budget)
+                    ci[u][j] = ok ? (unsigned)idx : zrow;
+#ifdef DSAT_EXP_GATHER_LOCAL   // timing experiment: every gathered row comes from a 64-row window
+                    ci[u][j] &= 63;
+#endif
                 }
 #pragma unroll
             for (int u = 0; u < PASSES; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (ci[u][j] >= 0) {
-                        cv[u][j] = ld4(a.closs4 + (size_t)ci[u][j] * F + sub * 4);
-                        vv[u][j] = ld4(a.vla + (size_t)ci[u][j] * F + sub * 4);
-                    }
+                for (int j = 0; j < GJ; ++j) {
+                    const unsigned o = ci[u][j] * (unsigned)F + (unsigned)sub * 4u;
+                    cv[u][j] = ld4(a.closs4 + o);
+                    vv[u][j] = ld4(a.vla + o);
+                }
 #pragma unroll
             for (int u = 0; u < PASSES; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (ci[u][j] >= 0) {
-                        M[u].x += cv[u][j].x; M[u].y += cv[u][j].y; M[u].z += cv[u][j].z; M[u].w += cv[u][j].w;
-                        VL[u].x += vv[u][j].x; VL[u].y += vv[u][j].y; VL[u].z += vv[u][j].z; VL[u].w += vv[u][j].w;
-                    }
+                for (int j = 0; j < GJ; ++j) {
+                    M[u].x += cv[u][j].x; M[u].y += cv[u][j].y; M[u].z += cv[u][j].z; M[u].w += cv[u][j].w;
+                    VL[u].x += vv[u][j].x; VL[u].y += vv[u][j].y; VL[u].z += vv[u][j].z; VL[u].w += vv[u][j].w;
+                }
         }
+        DSAT_STAMP(a, 6);
 #pragma unroll
         for (int u = 0; u < PASSES; ++u) {
             const int r = wave + u * ROUND_NWAVES;
@@ -670,18 +688,22 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
             float4 Mo;
             Mo.x = __shfl_xor(M[u].x, 32); Mo.y = __shfl_xor(M[u].y, 32);
             Mo.z = __shfl_xor(M[u].z, 32); Mo.w = __shfl_xor(M[u].w, 32);
-            if (half == 0) {   // closed form of the inner tape; closs4 = 4*closs, 0.25 is exact
-                const float4 qv = rowv[u];
+            {   // closed form of the inner tape (closs4 = 4*closs, 0.25 is exact); each half-wave
+                // computes two of its lane's four columns: half 0 -> .x .y, half 1 -> .z .w
+                const float4 qv = qrow[u];
                 const float vw = wv[u];
-                float4 g;
-                g.x = (-sigmoid_f(qv.x) * (M[u].x * 0.25f) + sigmoid_f(-qv.x) * (Mo.x * 0.25f)) * vw;
-                g.y = (-sigmoid_f(qv.y) * (M[u].y * 0.25f) + sigmoid_f(-qv.y) * (Mo.y * 0.25f)) * vw;
-                g.z = (-sigmoid_f(qv.z) * (M[u].z * 0.25f) + sigmoid_f(-qv.z) * (Mo.z * 0.25f)) * vw;
-                g.w = (-sigmoid_f(qv.w) * (M[u].w * 0.25f) + sigmoid_f(-qv.w) * (Mo.w * 0.25f)) * vw;
-                st4(sX + r * ldx + sub * 4, g);
-            } else {
-                st4(sX + r * ldx + OFF_V + sub * 4, rowv[u]);
+                const float q0 = half ? qv.z : qv.x, q1 = half ? qv.w : qv.y;
+                const float p0 = half ? Mo.z : M[u].x, p1 = half ? Mo.w : M[u].y;   // sums over +v clauses
+                const float n0 = half ? M[u].z : Mo.x, n1 = half ? M[u].w : Mo.y;   // sums over -v clauses
+                float s0, sn0, s1, sn1;
+                sigmoid_pair(q0, s0, sn0);
+                sigmoid_pair(q1, s1, sn1);
+                float2 g;
+                g.x = (-s0 * (p0 * 0.25f) + sn0 * (n0 * 0.25f)) * vw;
+                g.y = (-s1 * (p1 * 0.25f) + sn1 * (n1 * 0.25f)) * vw;
+                *reinterpret_cast<float2*>(sX + r * ldx + sub * 4 + 2 * half) = g;
             }
+            if (half == 1) st4(sX + r * ldx + OFF_V + sub * 4, rowv[u]);
         }
     }
     __syncthreads();

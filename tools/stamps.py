@@ -26,3 +26,7 @@ for k in range(3):
     print("P%d: %d tiles; per-tile cycles median total %.0f (max %.0f)" % (k + 1, tiles[k], np.median(tot), tot.max()))
     for i, nm in enumerate(names[k]):
         print("    %-14s median %8.0f  max %8.0f cycles" % (nm, np.median(d[:, i]), d[:, i].max()))
+    if k == 2:   # finer stamps inside the P3 gather (slots 4..6), thread 0's view
+        for nm, lo, hi in (("  meta", 0, 4), ("  stage+rows", 4, 5), ("  neighbour loop", 5, 6), ("  finish", 6, 1)):
+            dd = (t[:, hi] - t[:, lo]).astype(np.float64)
+            print("    %-16s median %8.0f  max %8.0f cycles" % (nm, np.median(dd), dd.max()))
