@@ -338,11 +338,15 @@ struct StaticLayer { const float4* wp; const float* bias; int kblocks, ntiles; }
 // whole tiles; wave NW/2 + i owns tile NW + i and row block i of the last tile.  Waves w and
 // w + NW/2 share a SIMD, so every SIMD gets 3*RB + 1 (tile, row block) units instead of the
 // 4*RB that "two tiles per wave, last wave idle" puts on the busiest one.
-template <int RB, int NW, int T0, int T1, int T2, bool MIX0 = false, typename Store>
+// `between()` runs after layer 0's weight ring has been requested and before the barrier that
+// publishes the input tile: the caller's last piece of tile preparation (the tail of a gather)
+// goes there, so the ring's L2 latency is hidden behind it.  With `sync_in` the chain takes
+// that barrier itself (the caller must not).
+template <int RB, int NW, int T0, int T1, int T2, bool MIX0 = false, typename Store, typename Between>
 __device__ __forceinline__ void chain_static(const StaticLayer& L0, const StaticLayer& L1, const StaticLayer& L2,
                                              const float* sIn, int ldin, float* bufA, int ldA, float* bufB,
                                              int ldB, int wv /* wave-uniform (SGPR) */, int lane,
-                                             Store&& final_store, bool sync_in) {
+                                             Store&& final_store, bool sync_in, Between&& between) {
     static_assert(!MIX0 || (T0 == 2 && RB == NW / 2), "MIX0 layout");
     constexpr int TL = T2 > 0 ? T2 : 1;
     const int t0 = wv * T0, t1 = wv * T1, t2 = wv * TL;
@@ -373,16 +377,19 @@ __device__ __forceinline__ void chain_static(const StaticLayer& L0, const Static
         unsigned vo0[T0];
         f32x4 r0[PrefetchDepth<T0>::value][T0];
         ring_prime_tiles<T0>(r0, vo0, L0.wp, L0.kblocks, tiles0, lane);
+        between();
         if (sync_in) lds_barrier();
         gemm_primed<RB, T0, MIX0>(sIn, ldin, L0.kblocks, L0.wp, r0, vo0, lane, acc0, sp_rb);
     } else if (on0) {
         unsigned vo0[T0];
         f32x4 r0[PrefetchDepth<T0>::value][T0];
         ring_prime_tiles<T0>(r0, vo0, L0.wp, L0.kblocks, tiles0, lane);
+        between();
         if (sync_in) lds_barrier();
         gemm_primed<RB, T0>(sIn, ldin, L0.kblocks, L0.wp, r0, vo0, lane, acc0);
-    } else if (sync_in) {
-        lds_barrier();
+    } else {
+        between();
+        if (sync_in) lds_barrier();
     }
     DSAT_PROBE(1);
     // biases were requested before layer 0; the queue is empty here (the k-loop drained it)
@@ -446,6 +453,14 @@ __device__ __forceinline__ void chain_static(const StaticLayer& L0, const Static
     } else {
         if (on1) layer_epilogue<RB, T1>(acc1, bv1, t1, L1.ntiles, 0, lane, final_store);
     }
+}
+
+template <int RB, int NW, int T0, int T1, int T2, bool MIX0 = false, typename Store>
+__device__ __forceinline__ void chain_static(const StaticLayer& L0, const StaticLayer& L1, const StaticLayer& L2,
+                                             const float* sIn, int ldin, float* bufA, int ldA, float* bufB,
+                                             int ldB, int wv, int lane, Store&& final_store, bool sync_in) {
+    chain_static<RB, NW, T0, T1, T2, MIX0>(L0, L1, L2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store,
+                                           sync_in, [] {});
 }
 
 inline int max_tpw_for_rb(int rb) { return rb == 1 ? 8 : rb == 2 ? 4 : 2; }

@@ -201,9 +201,12 @@ __device__ __forceinline__ void tile_colsums(int tile_lo, int rows, const TileMe
 
 // Runs the layers of one MLP on the tile: input in LDS, hidden activations ping-pong between
 // bufA/bufB, the last layer goes to `final_store(row, col, v)`.  Ends with a barrier.
-template <int RB, typename Store>
+// `prep()` is the caller's last piece of input-tile preparation; the chain runs it after asking
+// for its first weights, then takes the barrier that publishes the tile (the caller must not).
+template <int RB, typename Store, typename Prep>
 __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, int ldin, float* bufA, int ldA,
-                                          float* bufB, int ldB, int wave, int lane, Store&& final_store) {
+                                          float* bufB, int ldB, int wave, int lane, Store&& final_store,
+                                          Prep&& prep) {
     if (m.static_id != CHAIN_GENERIC) {   // blocking known at compile time: cross-layer weight prefetch
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const StaticLayer S0{m.L[0].wp, m.L[0].bias, m.L[0].kblocks, m.L[0].ntiles};
@@ -211,18 +214,20 @@ __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, 
         const StaticLayer S2{m.L[2].wp, m.L[2].bias, m.L[2].kblocks, m.L[2].ntiles};
         if constexpr (RB == 1) {
             if (m.static_id == CHAIN_442)
-                chain_static<1, ROUND_NWAVES, 4, 4, 2>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, false);
+                chain_static<1, ROUND_NWAVES, 4, 4, 2>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
             else
-                chain_static<1, ROUND_NWAVES, 2, 2, 1>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, false);
+                chain_static<1, ROUND_NWAVES, 2, 2, 1>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
         } else if constexpr (RB == 4) {
             if (m.static_id == CHAIN_22M)
-                chain_static<4, ROUND_NWAVES, 2, 2, 0, true>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, false);
+                chain_static<4, ROUND_NWAVES, 2, 2, 0, true>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
             else
-                chain_static<4, ROUND_NWAVES, 2, 2, 0>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, false);
+                chain_static<4, ROUND_NWAVES, 2, 2, 0>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
         }
         __syncthreads();
         return;
     }
+    prep();
+    __syncthreads();
     const float* in = sIn;
     int ld_in = ldin;
     for (int l = 0; l < m.nlayers; ++l) {
@@ -243,6 +248,12 @@ __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, 
         }
     }
     __syncthreads();
+}
+
+template <int RB, typename Store>
+__device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, int ldin, float* bufA, int ldA,
+                                          float* bufB, int ldB, int wave, int lane, Store&& final_store) {
+    run_chain<RB>(m, sIn, ldin, bufA, ldA, bufB, ldB, wave, lane, final_store, [] {});
 }
 
 // Two independent 2-layer chains side by side: waves [0, NW/2) run chain A, the others chain B
@@ -480,6 +491,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
         constexpr int U = ROWS;
         constexpr int GJ = 4;
         float4 S[U], M[U];
+        float rwv[U];
         int e0[U], e1[U];
         int nmax = 0;
 #pragma unroll
@@ -488,6 +500,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
             M[u] = S[u];
             const int r = hw + u * (NT / 32);
             e0[u] = 0; e1[u] = 0;
+            rwv[u] = tile_lo + r < tile_hi ? a.rev_w[tile_lo + r] : 0.f;
             if (tile_lo + r < tile_hi) {
                 if (staged) { e0[u] = sPtr[r]; e1[u] = sPtr[r + 1]; }
                 else { e0[u] = a.c_rowptr[tile_lo + r]; e1[u] = a.c_rowptr[tile_lo + r + 1]; }
@@ -525,25 +538,26 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
                     M[u].x += lv[u][j].x; M[u].y += lv[u][j].y; M[u].z += lv[u][j].z; M[u].w += lv[u][j].w;
                 }
         }
+        // the last part of the tile preparation runs inside the chain, after it has asked for
+        // its first weight fragments (run_chain's `prep`), and the chain takes the barrier
+        auto finish = [&]() {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int r = hw + u * (NT / 32);
             const int c = tile_lo + r;
             float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
-            float rw = 0.f;
             if (c < C) {
-                rw = a.rev_w[c];
                 cl = make_float4(4.f * expf(-S[u].x), 4.f * expf(-S[u].y), 4.f * expf(-S[u].z),
                                  4.f * expf(-S[u].w));
                 st4(a.closs4 + (size_t)c * F + sub * 4, cl);
             }
+            const float rw = rwv[u];
             st4(sX + r * ldx + F + sub * 4, make_float4(M[u].x * rw, M[u].y * rw, M[u].z * rw, M[u].w * rw));
             st4(sX + r * ldx + 2 * F + sub * 4, cl);
         }
-    }
-    __syncthreads();
-    DSAT_STAMP(a, 2);
-    {   // R8-R9: clause_data = clause_mlp([clause_state, clause_messages, clauses_loss])
+        DSAT_STAMP(a, 2);
+        };
+        // R8-R9: clause_data = clause_mlp([clause_state, clause_messages, clauses_loss])
         float* vla = a.vla;
         float* ncv = a.ncv;
         float* stage = sX;   // the input tile is dead once layer 0 has run
@@ -556,7 +570,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
                 st4(stage + row * lds + (col - F), v);
                 if (c < C) st4(ncv + (size_t)c * F + (col - F), v);
             }
-        });
+        }, finish);
         DSAT_STAMP(a, 3);
         tile_colsums<BM>(tile_lo, C, tm, a.cl_seg, a.psum_c_wr, stage, lds, sMean, tid);
         DSAT_STAMP(a, 4);
@@ -679,6 +693,9 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
                 }
         }
         DSAT_STAMP(a, 6);
+        // the last part of the tile preparation runs inside the chain, after it has asked for
+        // its first weight fragments (run_chain's `prep`), and the chain takes the barrier
+        auto finish = [&]() {
 #pragma unroll
         for (int u = 0; u < PASSES; ++u) {
             const int r = wave + u * ROUND_NWAVES;
@@ -705,10 +722,9 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
             }
             if (half == 1) st4(sX + r * ldx + OFF_V + sub * 4, rowv[u]);
         }
-    }
-    __syncthreads();
-    DSAT_STAMP(a, 1);
-    {   // R12: new_variables = update_gate(unit)
+        DSAT_STAMP(a, 1);
+        };
+        // R12: new_variables = update_gate(unit)
         float* newv = a.newv;
         float* stage = sX;
         const int lds = F + 8;
@@ -718,7 +734,7 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
                 st4(stage + row * lds + col, v);
                 if (n < N) st4(newv + (size_t)n * F + col, v);
             }
-        });
+        }, finish);
         DSAT_STAMP(a, 2);
         tile_colsums<BM>(tile_lo, N, tm, a.var_seg, a.psum_v, stage, lds, sPart, tid);
         DSAT_STAMP(a, 3);
