@@ -11,7 +11,7 @@ necessary, not sufficient; the GPU parity tests are the other half."""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "diffusionsat_amd", "csrc", sys.argv[1] if len(sys.argv) > 1 else "kernels_round.hip")
-out = "/tmp/kr_audit.s"
+out = "/tmp/kr_audit_%s_%d.s" % (os.path.basename(src), os.getpid())
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
                        "-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
 text = open(out).read()
@@ -72,4 +72,6 @@ for m in re.finditer(r"^(_ZN4dsat\S*(?:round_p\d|chain_kernel)\S*):[^\n]*\n(.*?)
     for ln, code, hit in bad[:12]:
         print("    line %d: %s   (pending v%s)" % (ln, code, hit))
     total_bad += len(bad)
+if not os.environ.get("DSAT_AUDIT_KEEP"):
+    os.remove(out)
 sys.exit(1 if total_bad else 0)
