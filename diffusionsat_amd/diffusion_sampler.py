@@ -71,6 +71,9 @@ class DiffusionSampler:
         self.inputs = GraphInputs(self.batch)
         self.seed, self.rank, self.world_size = int(seed), int(rank), int(world_size)
         self.success_rate = 0.0
+        # True: re-check every copy on the host like the reference's loop (:283-307); False: trust the
+        # device's per-copy SAT flag (tests/test_gpu_fullsize.py compares the two)
+        self.host_recheck = False
 
     def _decode(self, assignment: np.ndarray, counts: Dict[int, int], still_needed: int):
         """Per-graph loop of ``samples`` (:283-307): int-encode (bit i <-> x_{i+1}), re-check."""
@@ -89,6 +92,25 @@ class DiffusionSampler:
                     break
         return total, sat, still_needed
 
+    def _decode_flags(self, assignment: np.ndarray, solved: np.ndarray, counts: Dict[int, int], still_needed: int):
+        """Same result as ``_decode`` without the per-copy Python SAT check: the device already
+        evaluated every copy's clauses on exactly these bits (``solved``: the per-graph flag of
+        ``dsat_sample`` -- a copy is frozen at the step that satisfied it, so flag == satisfiable);
+        the bits are packed little-endian, bit i <-> x_{i+1} (utils/VariableAssignment.py:63-69)."""
+        n, g = self.n_vars, self.copies_per_batch
+        packed = np.packbits(assignment[: g * n].reshape(g, n).astype(np.uint8), axis=1, bitorder="little")
+        total = sat = 0
+        for i in range(g):
+            total += 1
+            if solved[i]:
+                sat += 1
+                key = int.from_bytes(packed[i].tobytes(), "little")
+                counts[key] = counts.get(key, 0) + 1
+                still_needed -= 1
+                if still_needed == 0:
+                    break
+        return total, sat, still_needed
+
     def samples(self, n_samples: int) -> Dict[int, int]:
         """:param n_samples: how many correct samples to generate
         :return: dict: solution as int => count   (satuniformity/DiffusionSampler.py:229-311)"""
@@ -101,8 +123,12 @@ class DiffusionSampler:
                 break
             # every batch (and every rank) draws from its own Philox sub-stream
             seed = self.seed + 1000003 * (it * self.world_size + self.rank) + 1
-            _, assignment, _ = diffusion(diffusion_steps, self.model, self.inputs, seed=seed)
-            t, s, needed = self._decode(assignment.cpu().numpy(), counts, needed)
+            _, assignment, var_correct = diffusion(diffusion_steps, self.model, self.inputs, seed=seed)
+            if self.host_recheck:
+                t, s, needed = self._decode(assignment.cpu().numpy(), counts, needed)
+            else:
+                solved = var_correct[:: self.n_vars].cpu().numpy() > 0.5     # one flag per copy
+                t, s, needed = self._decode_flags(assignment.cpu().numpy(), solved, counts, needed)
             total += t
             sat += s
             it += 1

@@ -156,6 +156,18 @@ def test_facade_query_sat_and_sampler(rt, tmp_path):
     res = smp.samples(25)
     assert sum(res.values()) == 25 and all(isinstance(k, int) and 0 <= k < 16 for k in res)
     assert smp.success_rate == 1.0
+    # the device's per-copy SAT flags give the same dictionary as the reference's host re-check
+    smp_h = DiffusionSampler(str(npz), str(cnf))
+    smp_h.host_recheck = True
+    assert smp_h.samples(25) == res
+    # a formula with few models (x1 & (x2|x3) & -x4): some copies fail, both decoders agree
+    few = tmp_path / "few.cnf"
+    DimacsFile(str(few), clauses=[[1], [2, 3], [-4]]).store()
+    a, b = DiffusionSampler(str(npz), str(few)), DiffusionSampler(str(npz), str(few))
+    b.host_recheck = True
+    ra, rb = a.samples(40), b.samples(40)
+    assert ra == rb and a.success_rate == b.success_rate
+    assert all(k & 1 and not (k >> 3) & 1 and (k >> 1) & 3 for k in ra)
     # an unsatisfiable formula stops by the 0.5 % rule and returns an empty dict
     bad = tmp_path / "unsat.cnf"
     DimacsFile(str(bad), clauses=[[1], [-1], [2, 1]]).store()
