@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one denoising step = one QuerySAT.diffusion_step of R=32 message-passing
-rounds over one 20k-node batch (BASELINE config 2: 31 distinct hard 3-SAT instances,
+rounds over one 20k-node batch (BASELINE config 2: 31 distinct solver-filtered threshold 3-SAT instances,
 n=100, m=428 -> N=3100 vars, C=13268 clauses, 19468 nodes), run inside the device-side
 sampler loop (randomized rounding -> step -> SAT check -> reverse step).  Inputs are
 resident in HBM before the timed region; the step runs with the reference's semantics
@@ -176,7 +176,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "solved_fraction": solved_fraction,
-            "config": {"workload": "BASELINE config 2: %d planted hard 3-SAT instances n=%d m=%d per GPU "
+            "config": {"workload": "BASELINE config 2: %d satisfiable threshold 3-SAT instances n=%d m=%d per GPU "
                                    "(N=%d vars, C=%d clauses, E=%d edges, %d nodes), R=%d rounds per denoising "
                                    "step, T=%d steps, random-init Glorot weights, device Philox noise, early exit "
                                    "armed (never fires)" % (batch.n_graphs, args.vars, len(instances[0][1]), n, c, e,

@@ -48,6 +48,7 @@ SIGNATURES = {
                                        _vp, _vp, _vp, _vp, _vp, _vp]),
     "dsat_diffusion_step_self": (C.c_int, [_vp, _f32, _vp, _vp, _vp, _vp, _u64, _u32, _i32, _i32,
                                             _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dsat_host_solve": (C.c_int, [_i32, _i32, _vp, _vp, C.c_int64, _vp, _vp]),
     "dsat_sample": (C.c_int, [_vp, _i32, _i32, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.POINTER(_f32), _vp]),
     "dsat_sample_self": (C.c_int, [_vp, _i32, _i32, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp,

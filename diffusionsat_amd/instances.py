@@ -1,10 +1,13 @@
 """Synthetic CNF instance generators for the benchmark/parity configurations.
 
 The reference's generators need cnfgen / python-sat / a prebuilt ``cgen`` binary
-(data/CNFGen.py, data/k_sat.py, data/SHAGen2019.py), none of which is available;
-these produce inputs of the same shape with a *planted* satisfying assignment
-instead of a solver filter (documented deviation).  All are
-seeded and pure NumPy.
+(data/CNFGen.py, data/k_sat.py, data/SHAGen2019.py), none of which is available.
+Two families live here, all seeded: *planted* stand-ins (pure NumPy: same shapes, a hidden
+satisfying assignment instead of a solver filter) and, at the end of the file, the
+reference's own distributions for threshold 3-SAT and NeuroSAT-style k-SAT, filtered by
+the extension's host-side CDCL solver (``dsat_host_solve``) in place of PySAT.  The SHA
+generator's ``cgen`` binary has no source in the reference: ``irregular_cnf`` stays a
+shape stand-in.
 """
 from __future__ import annotations
 
@@ -83,12 +86,104 @@ def irregular_cnf(n_vars: int = 10000, n_clauses: int = 60000, seed: int = 5,
     return n_vars, clauses, planted.astype(np.int32)
 
 
-def config2_instances(n_graphs: int = 31, n_vars: int = 100, seed: int = 2):
-    """31 distinct hard 3-SAT instances = 19 468 nodes (BASELINE config 2)."""
-    return [hard_3sat(n_vars, seed=seed * 1000 + i)[:2] for i in range(n_graphs)]
+def config2_instances(n_graphs: int = 31, n_vars: int = 100, seed: int = 2, planted: bool = False):
+    """31 distinct hard 3-SAT instances = 19 468 nodes (BASELINE config 2), drawn like the
+    reference's SAT_3 dataset (solver-filtered threshold 3-SAT, ``threshold_3sat``);
+    ``planted=True`` gives the planted stand-ins instead (no solver needed)."""
+    gen = hard_3sat if planted else threshold_3sat
+    return [gen(n_vars, seed=seed * 1000 + i)[:2] for i in range(n_graphs)]
 
 
-def config3_instances(n_copies: int = 256, n_vars: int = 100, seed: int = 2):
+def config3_instances(n_copies: int = 256, n_vars: int = 100, seed: int = 2, planted: bool = False):
     """One config-2 instance replicated (BASELINE config 3)."""
-    inst = hard_3sat(n_vars, seed=seed * 1000)[:2]
+    inst = (hard_3sat if planted else threshold_3sat)(n_vars, seed=seed * 1000)[:2]
     return [inst] * n_copies
+
+
+# ---------------------------------------------------------------------- solver-filtered generators
+# The reference's own distributions (SURVEY.md §8f N2): same clause draws as the planted stand-ins
+# above, but filtered by a SAT solver as the reference does -- here the host-side CDCL solver of
+# the extension (include/dsat.h: dsat_host_solve), since PySAT is not available.
+
+def solve(n_vars: int, clauses, conflict_limit: int = 0):
+    """SAT check of a CNF on the host.  Returns (True, model bits[n_vars]) / (False, None) /
+    (None, None) when ``conflict_limit`` (> 0) was reached."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    lens = np.fromiter((len(c) for c in clauses), dtype=np.int64, count=len(clauses))
+    rowptr = np.zeros(len(clauses) + 1, dtype=np.int32)
+    np.cumsum(lens, out=rowptr[1:])
+    lits = np.fromiter((l for c in clauses for l in c), dtype=np.int32, count=int(rowptr[-1]))
+    model = np.zeros(max(n_vars, 1), dtype=np.uint8)
+    res = C.c_int32(-2)
+    _lib.check(lib.dsat_host_solve(int(n_vars), len(clauses), rowptr.ctypes.data_as(C.c_void_p),
+                                   lits.ctypes.data_as(C.c_void_p), int(conflict_limit), C.byref(res),
+                                   model.ctypes.data_as(C.c_void_p)))
+    if res.value == 1:
+        return True, model[:n_vars].astype(np.int32)
+    return (False, None) if res.value == 0 else (None, None)
+
+
+def random_kcnf(n_vars: int, n_clauses: int, k: int, rng):
+    """cnfgen.RandomKCNF(k, n, m) as data/CNFGen.py:47 uses it: m distinct clauses, each over k
+    distinct variables with independent random signs."""
+    seen, clauses = set(), []
+    while len(clauses) < n_clauses:
+        vs = np.sort(rng.choice(n_vars, size=k, replace=False))
+        signs = rng.integers(0, 2, size=k)
+        c = tuple(int(v + 1) if s else -int(v + 1) for v, s in zip(vs, signs))
+        if c in seen:
+            continue
+        seen.add(c)
+        clauses.append(list(c))
+    return clauses
+
+
+def threshold_3sat(n_vars: int = 100, seed: int = 0):
+    """One draw of SAT_3_Instances._generator (data/CNFGen.py:40-58) for a fixed n: random 3-SAT
+    with m = int(4.258 n + 58.26 n^(-2/3)) clauses, redrawn until the solver finds it satisfiable.
+    Returns (n_vars, clauses, solution bits)."""
+    rng = np.random.default_rng(seed)
+    m = threshold_clause_count(n_vars)
+    while True:
+        clauses = random_kcnf(n_vars, m, 3, rng)
+        sat, model = solve(n_vars, clauses)
+        if sat:
+            return n_vars, clauses, model
+
+
+def sr_ksat(seed: int = 0, min_vars: int = 30, max_vars: int = 100, p_k_2: float = 0.3, p_geo: float = 0.4,
+            solutions_multiplier: float = 1.0):
+    """One draw of the NeuroSAT-style generator (data/k_sat.py:36-93): clauses of width
+    k = (1 w.p. p_k_2 else 2) + Geometric(p_geo) are added while the formula stays satisfiable; the
+    clause that makes it unsatisfiable gets its first literal negated (which makes the formula
+    satisfiable again, NeuroSAT's SR(n) pair), duplicates/subsumed clauses are removed, and with
+    ``solutions_multiplier`` > 1 some clauses are dropped to leave about that many times more models
+    (:66-84).  Returns (n_vars, clauses)."""
+    import math
+    from .dimacs import DimacsFile
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(min_vars, max_vars + 1))
+    clauses = []
+    while True:
+        k_base = 1 if rng.random() < p_k_2 else 2
+        k = k_base + int(rng.geometric(p_geo))
+        vs = rng.choice(n, size=min(n, k), replace=False)
+        c = [int(v + 1) if rng.random() < 0.5 else -int(v + 1) for v in vs]
+        sat, _ = solve(n, clauses + [c])
+        if sat:
+            clauses.append(c)
+        else:
+            clauses.append([-c[0]] + c[1:])
+            break
+    df = DimacsFile(clauses=clauses)
+    df.reduce_clauses()                      # also removes subsumed clauses (k_sat.py:100-103)
+    clauses = df.clauses()
+    if solutions_multiplier > 1:
+        m = len(clauses)
+        x = pow(2.0, n / m)
+        d = int(max(0, min(round(math.log(solutions_multiplier, x), 0), m - 1)))
+        drop = set(int(i) for i in rng.choice(m, size=d, replace=False))
+        clauses = [c for i, c in enumerate(clauses) if i not in drop]
+    return n, clauses

@@ -223,6 +223,16 @@ int dsat_session_read_stamps(dsat_session* s, int64_t* out, int64_t n);
 int dsat_session_profile(dsat_session* s, int32_t cap, const char** names, double* us_out,
                          int64_t* launches_out);
 
+/* ---- instance preparation (host only, no GPU needed) ------------------------------------------
+ * SAT/UNSAT (+ one model) of a CNF: the filter the reference's generators run through PySAT
+ * (data/CNFGen.py:44-58 keeps drawing threshold 3-SAT until satisfiable; data/k_sat.py:44-60 adds
+ * clauses until UNSAT).  clause_lits are signed DIMACS literals, clause c = [rowptr[c], rowptr[c+1]).
+ * *result_out: 1 satisfiable (model_out[v] = value of x_{v+1}, if non-NULL), 0 unsatisfiable,
+ * -1 conflict_limit (> 0) reached. */
+int dsat_host_solve(int32_t n_vars, int32_t n_clauses, const int32_t* clause_rowptr,
+                    const int32_t* clause_lits, int64_t conflict_limit, int32_t* result_out,
+                    uint8_t* model_out);
+
 #ifdef __cplusplus
 }
 #endif
