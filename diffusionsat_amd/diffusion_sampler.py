@@ -74,6 +74,9 @@ class DiffusionSampler:
         # True: re-check every copy on the host like the reference's loop (:283-307); False: trust the
         # device's per-copy SAT flag (tests/test_gpu_fullsize.py compares the two)
         self.host_recheck = False
+        # independent batches kept in flight by samples(); 1 = strictly one after the other
+        self.batches_in_flight = 2
+        self._slots = []
 
     def _decode(self, assignment: np.ndarray, counts: Dict[int, int], still_needed: int):
         """Per-graph loop of ``samples`` (:283-307): int-encode (bit i <-> x_{i+1}), re-check."""
@@ -111,26 +114,57 @@ class DiffusionSampler:
                     break
         return total, sat, still_needed
 
+    def _slots_for(self, k: int):
+        """k independent sessions over the same device graph and weights, each with its own HIP
+        stream: the batches of one ``samples`` call overlap on the GPU (a config-2-size batch
+        leaves a quarter of the CUs idle in every kernel)."""
+        while len(self._slots) < k:
+            sess = runtime.Session(self.inputs.graph, self.model.device_weights(), max_rounds=test_rounds,
+                                   device=self.model.device)
+            self._slots.append((sess, torch.cuda.Stream(device=self.model.device)))
+        return self._slots[:k]
+
     def samples(self, n_samples: int) -> Dict[int, int]:
         """:param n_samples: how many correct samples to generate
-        :return: dict: solution as int => count   (satuniformity/DiffusionSampler.py:229-311)"""
+        :return: dict: solution as int => count   (satuniformity/DiffusionSampler.py:229-311)
+
+        Batches are decoded in launch order with the reference's stopping rules, so the result does
+        not depend on ``batches_in_flight`` (with more than one in flight the work of at most
+        ``batches_in_flight - 1`` batches is discarded when the loop stops)."""
         counts: Dict[int, int] = {}
         total = sat = 0
         needed = int(n_samples)
+        slots = self._slots_for(max(1, int(self.batches_in_flight)))
+        pending = []          # (stream, output dict) in launch order
         it = 0
+
+        def launch():
+            nonlocal it
+            sess, stream = slots[it % len(slots)]
+            # every batch (and every rank) draws from its own Philox sub-stream
+            seed = self.seed + 1000003 * (it * self.world_size + self.rank) + 1
+            stream.wait_stream(torch.cuda.current_stream(self.model.device))
+            with torch.cuda.stream(stream):
+                out = sess.sample(diffusion_steps, test_rounds, seed=seed, early_exit=True,
+                                  want_solved_fraction=False, self_conditioning=self_supervised)
+            pending.append((stream, out))
+            it += 1
+
         while needed > 0:
             if total > 0 and sat / total < 0.005:           # :261-263 too many unsat samples
                 break
-            # every batch (and every rank) draws from its own Philox sub-stream
-            seed = self.seed + 1000003 * (it * self.world_size + self.rank) + 1
-            _, assignment, var_correct = diffusion(diffusion_steps, self.model, self.inputs, seed=seed)
+            while len(pending) < len(slots):
+                launch()
+            stream, out = pending.pop(0)
+            stream.synchronize()
+            assignment = out["assignment"].cpu().numpy()
             if self.host_recheck:
-                t, s, needed = self._decode(assignment.cpu().numpy(), counts, needed)
+                t, s, needed = self._decode(assignment, counts, needed)
             else:
-                solved = var_correct[:: self.n_vars].cpu().numpy() > 0.5     # one flag per copy
-                t, s, needed = self._decode_flags(assignment.cpu().numpy(), solved, counts, needed)
+                t, s, needed = self._decode_flags(assignment, out["solved"].cpu().numpy() > 0, counts, needed)
             total += t
             sat += s
-            it += 1
+        for stream, _ in pending:                           # drain what was launched ahead
+            stream.synchronize()
         self.success_rate = sat / total if total else 0.0
         return counts

@@ -167,6 +167,9 @@ def test_facade_query_sat_and_sampler(rt, tmp_path):
     b.host_recheck = True
     ra, rb = a.samples(40), b.samples(40)
     assert ra == rb and a.success_rate == b.success_rate
+    c = DiffusionSampler(str(npz), str(few))
+    c.batches_in_flight = 1                                  # sequential == pipelined
+    assert c.samples(40) == ra and c.success_rate == a.success_rate
     assert all(k & 1 and not (k >> 3) & 1 and (k >> 1) & 3 for k in ra)
     # an unsatisfiable formula stops by the 0.5 % rule and returns an empty dict
     bad = tmp_path / "unsat.cnf"
