@@ -672,9 +672,6 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
                     if (staged) idx = sIdx[e];              // LDS: reading past the list is harmless
                     else idx = ok ? a.l_clause[e] : 0;      // rare path (lists larger than the LDS budget)
                     ci[u][j] = ok ? (unsigned)idx : zrow;
-#ifdef DSAT_EXP_GATHER_LOCAL   // timing experiment: every gathered row comes from a 64-row window
-                    ci[u][j] &= 63;
-#endif
                 }
 #pragma unroll
             for (int u = 0; u < PASSES; ++u)
