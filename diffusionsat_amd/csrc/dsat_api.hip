@@ -431,8 +431,6 @@ struct dsat_session {
     // graph replay
     int use_graph = 1;
     hipStream_t cap_stream = nullptr;
-    hipStream_t side_stream = nullptr;   // select/SAT of round r-1 runs beside P2/P3 of round r
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
     // profiling
     int profile = 0;
@@ -684,9 +682,6 @@ extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, i
     DSAT_HIP(hipMalloc((void**)&s->slab, s->slab_bytes));
     hipError_t e = hipMemset(s->slab, 0, s->slab_bytes);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         (void)hipFree(s->slab);
         return hip_fail(e, "session init", __FILE__, __LINE__);
@@ -726,9 +721,6 @@ extern "C" void dsat_session_destroy(dsat_session* s) {
     for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->cap_stream) (void)hipStreamDestroy(s->cap_stream);
-    if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
-    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->slab) (void)hipFree(s->slab);
     if (s->stamps) (void)hipFree(s->stamps);
     delete s;

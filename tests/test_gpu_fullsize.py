@@ -201,3 +201,32 @@ def test_irregular_degree_graph_matches_oracle(rt):
     got = out["round_logits"].cpu().numpy()
     for r in range(rounds):
         assert np.abs(got[r] - ref["trace"]["logits"][r]).max() < 5e-4, r
+
+
+def test_two_batches_in_flight_do_not_disturb_each_other(rt):
+    """Two sessions over the same device graph and weights, on two HIP streams at once (what
+    samples() and bench.py --batches-in-flight do): each reproduces its solo run bit for bit."""
+    from diffusionsat_amd.batch import make_batch
+    from diffusionsat_amd.instances import config2_instances
+    batch = make_batch(config2_instances(31))
+    g, w = rt.Graph(batch), rt.Weights(oracle_weights(2))
+    T, R = 3, 32
+    solo = []
+    for seed in (11, 12):
+        s = rt.Session(g, w, max_rounds=R)
+        out = s.sample(T, R, seed=seed, early_exit=True, want_predictions=True, want_solved_fraction=False)
+        torch.cuda.synchronize()
+        solo.append((out["assignment"].clone(), out["predictions"].clone()))
+    assert not torch.equal(solo[0][1], solo[1][1])              # different seeds, different trajectories
+    sess = [rt.Session(g, w, max_rounds=R) for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(2):                                         # rep 0 captures the graphs, rep 1 replays them
+        outs = []
+        for s, st, seed in zip(sess, streams, (11, 12)):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append(s.sample(T, R, seed=seed, early_exit=True, want_predictions=True,
+                                     want_solved_fraction=False))
+        torch.cuda.synchronize()
+        for o, (a, p) in zip(outs, solo):
+            assert torch.equal(o["assignment"], a) and torch.equal(o["predictions"], p)
