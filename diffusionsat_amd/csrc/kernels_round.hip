@@ -407,10 +407,13 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
         const int n = tile_lo + row;
         if (n < N && col < F) {
             st4(q + (size_t)n * F + col, v);
-            st4(sp + (size_t)n * F + col,
-                make_float4(softplus_f(v.x), softplus_f(v.y), softplus_f(v.z), softplus_f(v.w)));
-            st4(sp + (size_t)(N + n) * F + col,
-                make_float4(softplus_f(-v.x), softplus_f(-v.y), softplus_f(-v.z), softplus_f(-v.w)));
+            // softplus(+-x) = max(+-x, 0) + log1p(exp(-|x|)): one transcendental pair serves both signs
+            const float4 t = make_float4(log1pf(expf(-fabsf(v.x))), log1pf(expf(-fabsf(v.y))),
+                                         log1pf(expf(-fabsf(v.z))), log1pf(expf(-fabsf(v.w))));
+            st4(sp + (size_t)n * F + col, make_float4(fmaxf(v.x, 0.f) + t.x, fmaxf(v.y, 0.f) + t.y,
+                                                      fmaxf(v.z, 0.f) + t.z, fmaxf(v.w, 0.f) + t.w));
+            st4(sp + (size_t)(N + n) * F + col, make_float4(fmaxf(-v.x, 0.f) + t.x, fmaxf(-v.y, 0.f) + t.y,
+                                                            fmaxf(-v.z, 0.f) + t.z, fmaxf(-v.w, 0.f) + t.w));
         }
     };
     if (a.round > 0 && !a.tail && a.mout.nlayers == 2 && a.mq.nlayers == 2) {
