@@ -22,8 +22,22 @@ namespace dsat {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Ring depth in k-blocks.  Measured on the whole denoising step (bench.py, config 2): depth 2-3
+// beats the deeper rings the stand-alone k-loop benchmark favoured (8-12 for narrow layers) by
+// 3-5 % -- an L2 hit returns within about one k-block of MFMA work, and every extra slot is a
+// load to issue at layer start and registers the k-loop cannot use.  -DDSAT_PD{1,2,4}=n override
+// the depth for 1, 2 and 3-4 tiles per wave (tools/exp_variants.sh).
+#ifndef DSAT_PD1
+#define DSAT_PD1 3
+#endif
+#ifndef DSAT_PD2
+#define DSAT_PD2 3
+#endif
+#ifndef DSAT_PD4
+#define DSAT_PD4 3
+#endif
 template <int TPW>
-struct PrefetchDepth { static constexpr int value = TPW >= 8 ? 3 : TPW >= 6 ? 4 : TPW >= 3 ? 5 : TPW >= 2 ? 8 : 12; };
+struct PrefetchDepth { static constexpr int value = TPW >= 6 ? 3 : TPW >= 3 ? DSAT_PD4 : TPW >= 2 ? DSAT_PD2 : DSAT_PD1; };
 
 // Weight-fragment loads are inline asm: hipcc (ROCm 7.2) otherwise proves that a register
 // prefetched PD iterations ahead equals a fresh load from the (read-only) weights and
