@@ -586,7 +586,10 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
     if (a.check_done && a.ctl->done != 0) return;
     constexpr int BM = ROUND_BM_VAR;
     constexpr int PASSES = BM / ROUND_NWAVES;   // variables per wave
-    constexpr int GJ = 8;                       // clause rows in flight per literal (x PASSES x 2 arrays)
+#ifndef DSAT_GJ3
+#define DSAT_GJ3 4
+#endif
+    constexpr int GJ = DSAT_GJ3;                // clause rows in flight per literal (x PASSES x 2 arrays)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.N;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
