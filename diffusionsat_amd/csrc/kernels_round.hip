@@ -88,6 +88,14 @@ __device__ __forceinline__ TileMetaDev load_meta(const int32_t* meta, int tile) 
     return m;
 }
 
+// Keeps the compiler from sinking the tile-record load below the early-exit branch: both
+// scalar loads are in flight when the flag is tested.
+__device__ __forceinline__ int both_arrived(int done, const TileMetaDev& m) {
+    int d = done, g = m.g_first;
+    asm volatile("" : "+s"(d), "+s"(g));
+    return d;
+}
+
 // state = 0.25*PairNorm(x) + 0.1*state for the rows of one tile (layers/normalization.py:43-71,
 // query_sat.py:265-266 / :279-280), then the :347-348 mix for the copy that enters the next
 // round.  sState[.][0..127] receives the carried state, sLogit (optional) the pre-mix value.
@@ -361,16 +369,20 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
 // PairNorm of the previous round (it depends on P2(r-1) only), off P2's critical path.
 __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
-    if (a.check_done && a.ctl->done != 0) return;
     constexpr int BM = ROUND_BM_VAR;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.N;
     const int vtiles = (N + BM - 1) / BM;
-    if ((int)blockIdx.x >= vtiles) {
+    const bool extra = (int)blockIdx.x >= vtiles;
+    const int tile = extra ? 0 : xcd_tile(blockIdx.x, vtiles);
+    // the early-exit flag and the tile record are requested together: one memory latency, not two
+    const int done = a.check_done ? a.ctl->done : 0;
+    const TileMetaDev tm = load_meta(a.vmeta, tile);
+    if (both_arrived(done, tm) != 0) return;
+    if (extra) {
         clause_norm_block(a, blockIdx.x - vtiles, a.cn_blocks, smem, tid);
         return;
     }
-    const int tile = xcd_tile(blockIdx.x, vtiles);
     const int tile_lo = tile * BM;
     float* sX = smem + a.off_x;
     float* sVlog = smem + a.off_vlog;
@@ -380,7 +392,6 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     const int ldx = a.ld_x, ldv = F + 8;
 
     DSAT_STAMP(a, 0);
-    const TileMetaDev tm = load_meta(a.vmeta, tile);
     if (tid < BM) {   // aux columns of v1 for this round (independent of everything else)
         const int n = tile_lo + tid;
         load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N && !a.tail);
@@ -444,19 +455,22 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
 template <int RB>
 __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
-    if (a.check_done && a.ctl->done != 0) return;
     constexpr int BM = 16 * RB;
     constexpr int ROWS = BM / (NT / 32);   // clause rows per half-wave
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int C = a.C, N = a.N;
     const int tiles = (C + BM - 1) / BM;
-    if ((int)blockIdx.x >= tiles) {
+    const bool extra = (int)blockIdx.x >= tiles;
+    const int tile = extra ? 0 : xcd_tile(blockIdx.x, tiles);
+    const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
+    const TileMetaDev tm = load_meta(a.cmeta, tile);
+    if (both_arrived(done, tm) != 0) return;
+    if (extra) {
         select_sat_body<NT>(blockIdx.x - tiles, a.G, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
                             a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, N, a.round - 1, a.check_done,
                             smem);
         return;
     }
-    const int tile = xcd_tile(blockIdx.x, tiles);
     const int tile_lo = tile * BM;
     const int tile_hi = min(tile_lo + BM, C);
     float* sX = smem + a.off_x;
@@ -466,7 +480,6 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
     const int ldx = a.ld_x;
 
     DSAT_STAMP(a, 0);
-    const TileMetaDev tm = load_meta(a.cmeta, tile);
     // the clause rows' literal lists -> LDS (sA is free until the first layer writes it)
     int* sPtr = reinterpret_cast<int*>(sA);
     int* sIdx = sPtr + BM + 8;
@@ -583,7 +596,6 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
 // ------------------------------------------------------------------------------------- P3
 __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
-    if (a.check_done && a.ctl->done != 0) return;
     constexpr int BM = ROUND_BM_VAR;
     constexpr int PASSES = BM / ROUND_NWAVES;   // variables per wave
 #ifndef DSAT_GJ3
@@ -593,6 +605,9 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.N;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
+    const TileMetaDev tm = load_meta(a.vmeta, tile);
+    if (both_arrived(done, tm) != 0) return;
     const int tile_lo = tile * BM;
     const int tile_hi = min(tile_lo + BM, N);
     float* sX = smem + a.off_x;
@@ -603,7 +618,6 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
     // unit = [variables_grad | variables | aux | loss_pos | loss_neg]        (query_sat.py:277)
     constexpr int OFF_V = F, OFF_AUX = 2 * F, OFF_POS = 2 * F + AUX_W, OFF_NEG = 3 * F + AUX_W;
     DSAT_STAMP(a, 0);
-    const TileMetaDev tm = load_meta(a.vmeta, tile);
     DSAT_STAMP(a, 4);
     {   // R4 + R11: one wave per variable, half 0 = literal +v, half 1 = literal -v
         const int sub = lane & 31, half = lane >> 5;
