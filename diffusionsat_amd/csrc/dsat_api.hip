@@ -538,8 +538,9 @@ static ChainSpec make_chain(const std::vector<PackedLayer>& layers, int rb) {
         // column tiles that hold real outputs (npad is rounded to 32 for the per-layer GEMM path;
         // the fragment-ordered weights are tile-major, so trailing all-padding tiles are just not visited)
         c.L[l].ntiles = (layers[l].out_dim + 15) / 16;
-        c.L[l].tpw = pick_tpw(c.L[l].ntiles, ROUND_NWAVES, max_tpw_for_rb(rb));
-        c.L[l].tpw_half = pick_tpw(c.L[l].ntiles, ROUND_NWAVES / 2, max_tpw_for_rb(rb));
+        const int cap = std::min(max_tpw_for_rb(rb), ROUND_TPW_CAP);
+        c.L[l].tpw = pick_tpw(c.L[l].ntiles, ROUND_NWAVES, cap);
+        c.L[l].tpw_half = pick_tpw(c.L[l].ntiles, ROUND_NWAVES / 2, cap);
     }
     // compile-time blockings (single pass per layer): see chain_static in fused_common.h
     auto matches = [&](bool half, std::initializer_list<int> tp) {
@@ -554,15 +555,18 @@ static ChainSpec make_chain(const std::vector<PackedLayer>& layers, int rb) {
         return true;
     };
     if (getenv("DSAT_NO_STATIC_CHAIN") == nullptr) {
-        if (rb == 1 && matches(false, {4, 4, 2})) c.static_id = CHAIN_442;
+        const bool mix_ok = getenv("DSAT_NO_MIX") == nullptr;
+        if (rb == 1 && ROUND_TPW_CAP >= 4 && matches(false, {4, 4, 2})) c.static_id = CHAIN_442;
         if (rb == 1 && matches(false, {2, 2, 1})) c.static_id = CHAIN_221;
-        if (rb == 4 && matches(false, {2, 2})) {
-            c.static_id = CHAIN_22;
-            // 13 column tiles on 8 waves: balanced (tile, row block) split, see chain_static MIX0
-            if (c.L[0].ntiles == 3 * ROUND_NWAVES / 2 + 1 && getenv("DSAT_NO_MIX") == nullptr) c.static_id = CHAIN_22M;
-        }
+        if (rb == 1 && ROUND_NWAVES == 16 && matches(false, {1, 1, 1})) c.static_id = CHAIN_111;
+        // RB 4: 13 column tiles get the balanced (tile, row block) split, see chain_static MIX0
+        if (rb == 4 && ROUND_NWAVES == 8 && matches(false, {2, 2}))
+            c.static_id = (mix_ok && c.L[0].ntiles == (ROUND_NWAVES - 4) * 2 + 4 + 1) ? CHAIN_22M : CHAIN_22;
+        if (rb == 4 && ROUND_NWAVES == 16 && matches(false, {1, 1}))
+            c.static_id = (mix_ok && c.L[0].ntiles == ROUND_NWAVES - 4 + 1) ? CHAIN_11M : CHAIN_11;
         if (rb == 1 && matches(true, {2, 1})) c.static_half_id = CHAIN_H21;
         if (rb == 1 && matches(true, {3, 2})) c.static_half_id = CHAIN_H32;
+        if (rb == 1 && matches(true, {1, 1})) c.static_half_id = CHAIN_H11;
     }
     if (getenv("DSAT_DEBUG_PLAN") != nullptr) {
         fprintf(stderr, "[dsat] chain rb=%d layers=%d static=%d half=%d :", rb, c.nlayers, c.static_id, c.static_half_id);
@@ -621,7 +625,7 @@ static bool plan_round(dsat_session* s) {
         int rb = 4;
         for (; rb >= 1; rb >>= 1) {
             const int bm = 16 * rb;
-            const int need = bm * (3 * F + 8) + bm * (hid + 8) * (layers.size() > 2 ? 2 : 1) + 512;
+            const int need = bm * (3 * F + 8) + bm * (hid + 8) * (layers.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64;
             if (need <= LDS) break;
         }
         ok = ok && rb >= 1;
@@ -649,7 +653,7 @@ static bool plan_round(dsat_session* s) {
         r.off_a = ROUND_BM_VAR * r.ld_x;
         r.off_b = r.off_a + ROUND_BM_VAR * r.ld_a;
         r.off_mean = r.off_b + ROUND_BM_VAR * r.ld_b;
-        ok = ok && (r.off_mean + 512 <= LDS);
+        ok = ok && (r.off_mean + ROUND_NWAVES * 64 <= LDS);
     }
     return ok;
 }
@@ -667,7 +671,7 @@ extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, i
         const int hid = max_hidden_pad(cl);
         int rb = 4;
         for (; rb > 1; rb >>= 1)
-            if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + 512 <= 40960) break;
+            if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64 <= 40960) break;
         s->p2_rb = rb;
         build_segments(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg);
         build_segments(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg);

@@ -160,7 +160,8 @@ hipError_t launch_chain(const ChainArgs& a, int rb, int nwaves, hipStream_t st);
 //   P3 var tile   : clause->literal gather (R4, R11), update_gate chain (R12), column sums
 // static_id / static_half_id: which compile-time blocking of fused_common.h's chain_static the
 // chain matches when all NW (resp. NW/2) waves run it; 0 = none (generic per-layer path).
-enum { CHAIN_GENERIC = 0, CHAIN_442 = 1, CHAIN_221 = 2, CHAIN_22 = 3, CHAIN_H21 = 4, CHAIN_H32 = 5, CHAIN_22M = 6 };
+enum { CHAIN_GENERIC = 0, CHAIN_442 = 1, CHAIN_221 = 2, CHAIN_22 = 3, CHAIN_H21 = 4, CHAIN_H32 = 5, CHAIN_22M = 6,
+       CHAIN_111 = 7, CHAIN_11 = 8, CHAIN_11M = 9, CHAIN_H11 = 10 };
 struct ChainSpec { ChainLayer L[4]; int nlayers; int static_id, static_half_id; };
 struct RoundArgs {
     // graph
@@ -198,7 +199,17 @@ struct RoundArgs {
 };
 constexpr int TILE_META_INTS = 16;
 constexpr int ROUND_BM_VAR = 16;    // rows per variable-side tile
-constexpr int ROUND_NWAVES = 8;
+// Waves per workgroup of the round kernels (8 or 16; one workgroup per CU either way).  16 = four
+// waves per SIMD at <= 128 VGPRs each: with the shallow weight ring that fits, and the tile
+// preparation (gathers, PairNorm) and the layer boundaries hide twice as much latency: +5 % on the
+// denoising step against 8 waves at <= 256 VGPRs (bench.py, config 2; build with
+// -DDSAT_ROUND_NWAVES=8 to compare).
+#ifndef DSAT_ROUND_NWAVES
+#define DSAT_ROUND_NWAVES 16
+#endif
+constexpr int ROUND_NWAVES = DSAT_ROUND_NWAVES;
+static_assert(ROUND_NWAVES == 8 || ROUND_NWAVES == 16, "round kernels are written for 8 or 16 waves");
+constexpr int ROUND_TPW_CAP = ROUND_NWAVES >= 16 ? 2 : 8;   // tiles per wave the round kernels are built for
 hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st);
 hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st);
 hipError_t launch_round_p3(const RoundArgs& a, hipStream_t st);

@@ -25,13 +25,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Ring depth in k-blocks.  Measured on the whole denoising step (bench.py, config 2): depth 2-3
 // beats the deeper rings the stand-alone k-loop benchmark favoured (8-12 for narrow layers) by
 // 3-5 % -- an L2 hit returns within about one k-block of MFMA work, and every extra slot is a
-// load to issue at layer start and registers the k-loop cannot use.  -DDSAT_PD{1,2,4}=n override
-// the depth for 1, 2 and 3-4 tiles per wave (tools/exp_variants.sh).
+// load to issue at layer start and registers the k-loop cannot use.  With 16 waves per workgroup
+// (four per SIMD) depth 2 is best at two tiles per wave, depth 3 at one; depth 1 (no look-ahead)
+// loses 10 %.  -DDSAT_PD{1,2,4}=n override the depth for 1, 2 and 3-4 tiles per wave.
 #ifndef DSAT_PD1
 #define DSAT_PD1 3
 #endif
 #ifndef DSAT_PD2
-#define DSAT_PD2 3
+#define DSAT_PD2 2
 #endif
 #ifndef DSAT_PD4
 #define DSAT_PD4 3
@@ -321,13 +322,15 @@ __device__ __forceinline__ void dense_layer_tpw(const float* __restrict__ sIn, i
 }
 
 // `tpw` (tiles per wave and pass, chosen on the host by pick_tpw) selects the register blocking.
-template <int RB, int NWAVES, typename Store>
+template <int RB, int NWAVES, int CAP = 8, typename Store>
 __device__ __forceinline__ void dense_layer(const float* __restrict__ sIn, int ldin, int kblocks,
                                             const float4* __restrict__ wp, const float* __restrict__ bias,
                                             int ntiles, int tpw, int act, int wave, int lane, Store&& store,
                                             bool sync_in = false) {
     // register budget: RB * TPW accumulators of 4 VGPRs + PD * TPW weight fragments in flight
-    constexpr int MAXT = RB == 1 ? 8 : RB == 2 ? 4 : 2;
+    // (CAP: kernels launched with 16 waves have half the registers per wave)
+    constexpr int MAXT0 = RB == 1 ? 8 : RB == 2 ? 4 : 2;
+    constexpr int MAXT = MAXT0 < CAP ? MAXT0 : CAP;
     if constexpr (MAXT >= 8) {
         if (tpw == 8) { dense_layer_tpw<RB, 8, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store, sync_in); return; }
         if (tpw == 6) { dense_layer_tpw<RB, 6, NWAVES>(sIn, ldin, kblocks, wp, bias, ntiles, act, wave, lane, store, sync_in); return; }
@@ -348,10 +351,11 @@ __device__ __forceinline__ void dense_layer(const float* __restrict__ sIn, int l
 // Layer l reads in_l (sIn, bufA, bufB) and hidden layers write bufA, then bufB.
 struct StaticLayer { const float4* wp; const float* bias; int kblocks, ntiles; };
 
-// MIX0 (layer 0 has 3*NW/2 + 1 column tiles, T0 == 2, RB == NW/2): waves [0, NW/2) own two
-// whole tiles; wave NW/2 + i owns tile NW + i and row block i of the last tile.  Waves w and
-// w + NW/2 share a SIMD, so every SIMD gets 3*RB + 1 (tile, row block) units instead of the
-// 4*RB that "two tiles per wave, last wave idle" puts on the busiest one.
+// MIX0 (RB == 4; layer 0 has (NW-4)*T0 + 4*(T0-1) + 1 column tiles, e.g. 13 for NW = 8, T0 = 2 and
+// for NW = 16, T0 = 1): waves [0, NW-4) own T0 whole tiles; wave NW-4+i owns T0-1 whole tiles and
+// row block i of the last tile.  Waves w, w+4, ... share a SIMD and NW-4 is a multiple of 4, so
+// every SIMD gets 3*RB + 1 = 13 (tile, row block) units instead of the 16 that whole tiles per
+// wave put on the busiest one.
 // `between()` runs after layer 0's weight ring has been requested and before the barrier that
 // publishes the input tile: the caller's last piece of tile preparation (the tail of a gather)
 // goes there, so the ring's L2 latency is hidden behind it.  With `sync_in` the chain takes
@@ -361,16 +365,21 @@ __device__ __forceinline__ void chain_static(const StaticLayer& L0, const Static
                                              const float* sIn, int ldin, float* bufA, int ldA, float* bufB,
                                              int ldB, int wv /* wave-uniform (SGPR) */, int lane,
                                              Store&& final_store, bool sync_in, Between&& between) {
-    static_assert(!MIX0 || (T0 == 2 && RB == NW / 2), "MIX0 layout");
+    static_assert(!MIX0 || (RB == 4 && NW % 4 == 0 && NW > 4), "MIX0 layout");
     constexpr int TL = T2 > 0 ? T2 : 1;
+    constexpr int NFULL = NW - 4;      // MIX0: waves that own whole tiles only
     const int t0 = wv * T0, t1 = wv * T1, t2 = wv * TL;
-    const bool mixed = MIX0 && wv >= NW / 2;
+    const bool mixed = MIX0 && wv >= NFULL;
     const bool on0 = MIX0 || t0 < L0.ntiles, on1 = t1 < L1.ntiles, on2 = T2 > 0 && t2 < L2.ntiles;
     int tiles0[T0];
 #pragma unroll
     for (int j = 0; j < T0; ++j) tiles0[j] = t0 + j < L0.ntiles ? t0 + j : L0.ntiles - 1;
-    if (mixed) { tiles0[0] = NW + (wv - NW / 2); tiles0[T0 - 1] = 3 * NW / 2; }
-    const int sp_rb = mixed ? wv - NW / 2 : 0;
+    if (mixed) {
+#pragma unroll
+        for (int j = 0; j + 1 < T0; ++j) tiles0[j] = NFULL * T0 + (wv - NFULL) * (T0 - 1) + j;
+        tiles0[T0 - 1] = L0.ntiles - 1;
+    }
+    const int sp_rb = mixed ? wv - NFULL : 0;
     float4 bv0[T0], bv1[T1], bv2[TL];
     if (on0) {
 #pragma unroll

@@ -107,7 +107,7 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
                                               const float* __restrict__ psum, const float* __restrict__ x,
                                               float* __restrict__ state, bool first, float* sState, int ldS,
                                               float* sLogit, int ldL, float* sMean, int tid) {
-    constexpr int ROWS = BM / (NT / 32);
+    constexpr int ROWS = (BM + NT / 32 - 1) / (NT / 32);
     const int tile_hi = min(tile_lo + BM, rows);
     const int sub = tid & 31, hw = tid >> 5;
     // padding rows of the last tile: finite zeros for the MFMAs
@@ -220,16 +220,26 @@ __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, 
         const StaticLayer S0{m.L[0].wp, m.L[0].bias, m.L[0].kblocks, m.L[0].ntiles};
         const StaticLayer S1{m.L[1].wp, m.L[1].bias, m.L[1].kblocks, m.L[1].ntiles};
         const StaticLayer S2{m.L[2].wp, m.L[2].bias, m.L[2].kblocks, m.L[2].ntiles};
-        if constexpr (RB == 1) {
+        if constexpr (RB == 1 && ROUND_NWAVES == 8) {
             if (m.static_id == CHAIN_442)
-                chain_static<1, ROUND_NWAVES, 4, 4, 2>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
+                chain_static<1, 8, 4, 4, 2>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
             else
-                chain_static<1, ROUND_NWAVES, 2, 2, 1>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
-        } else if constexpr (RB == 4) {
+                chain_static<1, 8, 2, 2, 1>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
+        } else if constexpr (RB == 1 && ROUND_NWAVES == 16) {
+            if (m.static_id == CHAIN_221)
+                chain_static<1, 16, 2, 2, 1>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
+            else
+                chain_static<1, 16, 1, 1, 1>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
+        } else if constexpr (RB == 4 && ROUND_NWAVES == 8) {
             if (m.static_id == CHAIN_22M)
-                chain_static<4, ROUND_NWAVES, 2, 2, 0, true>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
+                chain_static<4, 8, 2, 2, 0, true>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
             else
-                chain_static<4, ROUND_NWAVES, 2, 2, 0>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
+                chain_static<4, 8, 2, 2, 0>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
+        } else if constexpr (RB == 4 && ROUND_NWAVES == 16) {
+            if (m.static_id == CHAIN_11M)
+                chain_static<4, 16, 1, 1, 0, true>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
+            else
+                chain_static<4, 16, 1, 1, 0>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
         }
         __syncthreads();
         return;
@@ -246,12 +256,12 @@ __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, 
         if (l + 1 < m.nlayers) {
             float* o = (l & 1) ? bufB : bufA;
             const int ldo = (l & 1) ? ldB : ldA;
-            dense_layer<RB, ROUND_NWAVES>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
+            dense_layer<RB, ROUND_NWAVES, ROUND_TPW_CAP>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
                                           [=](int row, int col, float4 v) { st4(o + row * ldo + col, v); }, sync_in);
             in = o;
             ld_in = ldo;
         } else {
-            dense_layer<RB, ROUND_NWAVES>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 0, wave, lane,
+            dense_layer<RB, ROUND_NWAVES, ROUND_TPW_CAP>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 0, wave, lane,
                                           final_store, sync_in);
         }
     }
@@ -274,30 +284,38 @@ __device__ __forceinline__ void run_chain_pair(const ChainSpec& ma, const float*
                                                int wave, int lane, StoreA&& storeA, StoreB&& storeB) {
     constexpr int H = ROUND_NWAVES / 2;
     const int wv = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform for the compiler: the
-    if (ma.static_half_id == CHAIN_H21 && mb.static_half_id == CHAIN_H32) {
+    constexpr int WANT_A = ROUND_NWAVES == 8 ? CHAIN_H21 : CHAIN_H11;   // variables_output on H waves
+    constexpr int WANT_B = ROUND_NWAVES == 8 ? CHAIN_H32 : CHAIN_H21;   // variables_query on H waves
+    if (ma.static_half_id == WANT_A && mb.static_half_id == WANT_B) {
         const StaticLayer none{nullptr, nullptr, 0, 0};
         if (wv < H) {
             const StaticLayer S0{ma.L[0].wp, ma.L[0].bias, ma.L[0].kblocks, ma.L[0].ntiles};
             const StaticLayer S1{ma.L[1].wp, ma.L[1].bias, ma.L[1].kblocks, ma.L[1].ntiles};
-            chain_static<1, H, 2, 1, 0>(S0, S1, none, sInA, ldinA, bufA, ldA, nullptr, 0, wv, lane, storeA, false);
+            if constexpr (ROUND_NWAVES == 8)
+                chain_static<1, H, 2, 1, 0>(S0, S1, none, sInA, ldinA, bufA, ldA, nullptr, 0, wv, lane, storeA, false);
+            else
+                chain_static<1, H, 1, 1, 0>(S0, S1, none, sInA, ldinA, bufA, ldA, nullptr, 0, wv, lane, storeA, false);
         } else {
             const StaticLayer S0{mb.L[0].wp, mb.L[0].bias, mb.L[0].kblocks, mb.L[0].ntiles};
             const StaticLayer S1{mb.L[1].wp, mb.L[1].bias, mb.L[1].kblocks, mb.L[1].ntiles};
-            chain_static<1, H, 3, 2, 0>(S0, S1, none, sInB, ldinB, bufB, ldB, nullptr, 0, wv - H, lane, storeB, false);
+            if constexpr (ROUND_NWAVES == 8)
+                chain_static<1, H, 3, 2, 0>(S0, S1, none, sInB, ldinB, bufB, ldB, nullptr, 0, wv - H, lane, storeB, false);
+            else
+                chain_static<1, H, 2, 1, 0>(S0, S1, none, sInB, ldinB, bufB, ldB, nullptr, 0, wv - H, lane, storeB, false);
         }
         __syncthreads();
         return;
     }
     if (wv < H) {                                          // weight base must stay in SGPRs
-        dense_layer<1, H>(sInA, ldinA, ma.L[0].kblocks, ma.L[0].wp, ma.L[0].bias, ma.L[0].ntiles, ma.L[0].tpw_half, 1,
+        dense_layer<1, H, ROUND_TPW_CAP>(sInA, ldinA, ma.L[0].kblocks, ma.L[0].wp, ma.L[0].bias, ma.L[0].ntiles, ma.L[0].tpw_half, 1,
                           wv, lane, [=](int row, int col, float4 v) { st4(bufA + row * ldA + col, v); });
-        dense_layer<1, H>(bufA, ldA, ma.L[1].kblocks, ma.L[1].wp, ma.L[1].bias, ma.L[1].ntiles, ma.L[1].tpw_half, 0,
+        dense_layer<1, H, ROUND_TPW_CAP>(bufA, ldA, ma.L[1].kblocks, ma.L[1].wp, ma.L[1].bias, ma.L[1].ntiles, ma.L[1].tpw_half, 0,
                           wv, lane, storeA, true);
         __syncthreads();
     } else {
-        dense_layer<1, H>(sInB, ldinB, mb.L[0].kblocks, mb.L[0].wp, mb.L[0].bias, mb.L[0].ntiles, mb.L[0].tpw_half, 1,
+        dense_layer<1, H, ROUND_TPW_CAP>(sInB, ldinB, mb.L[0].kblocks, mb.L[0].wp, mb.L[0].bias, mb.L[0].ntiles, mb.L[0].tpw_half, 1,
                           wv - H, lane, [=](int row, int col, float4 v) { st4(bufB + row * ldB + col, v); });
-        dense_layer<1, H>(bufB, ldB, mb.L[1].kblocks, mb.L[1].wp, mb.L[1].bias, mb.L[1].ntiles, mb.L[1].tpw_half, 0,
+        dense_layer<1, H, ROUND_TPW_CAP>(bufB, ldB, mb.L[1].kblocks, mb.L[1].wp, mb.L[1].bias, mb.L[1].ntiles, mb.L[1].tpw_half, 0,
                           wv - H, lane, storeB, true);
         __syncthreads();
     }
@@ -456,7 +474,7 @@ template <int RB>
 __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     constexpr int BM = 16 * RB;
-    constexpr int ROWS = BM / (NT / 32);   // clause rows per half-wave
+    constexpr int ROWS = (BM + NT / 32 - 1) / (NT / 32);   // clause rows per half-wave
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int C = a.C, N = a.N;
     const int tiles = (C + BM - 1) / BM;
