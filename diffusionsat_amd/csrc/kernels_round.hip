@@ -523,7 +523,10 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
     {
         const int sub = tid & 31, hw = tid >> 5;
         constexpr int U = ROWS;
-        constexpr int GJ = 4;
+#ifndef DSAT_GJ2
+#define DSAT_GJ2 4
+#endif
+        constexpr int GJ = DSAT_GJ2;   // literal rows in flight per clause (x U rows x 2 arrays)
         float4 S[U], M[U];
         float rwv[U];
         int e0[U], e1[U];
