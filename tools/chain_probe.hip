@@ -2,18 +2,21 @@
 // layer, s_memtime stamps at layer entry (0), ring primed (4), main loop done (5), k-loop done
 // (1), epilogue done (2), barrier passed (3).  Usage: chain_probe [rb] [blocks] dims...
 #include <hip/hip_runtime.h>
+#ifndef PNW
+#define PNW 8
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
 // stamps go to LDS (lgkmcnt), never to global memory: a global store would join the vmcnt
 // queue that the weight ring counts by hand
-extern __shared__ long long s_probe_dyn[];            // [8 waves][64 records] (id, time) + counters
-#define PROBE_SLOTS 64
+extern __shared__ long long s_probe_dyn[];            // [PNW waves][PROBE_SLOTS records] (id, time) + counters
+#define PROBE_SLOTS 32
 #define DSAT_PROBE(id)                                                                     \
     do {                                                                                   \
         if ((threadIdx.x & 63) == 0) {                                                     \
-            int* cnt = reinterpret_cast<int*>(s_probe_dyn + 8 * PROBE_SLOTS) + (threadIdx.x >> 6); \
+            int* cnt = reinterpret_cast<int*>(s_probe_dyn + PNW * PROBE_SLOTS) + (threadIdx.x >> 6); \
             const int c = *cnt;                                                            \
             if (c < PROBE_SLOTS) s_probe_dyn[(threadIdx.x >> 6) * PROBE_SLOTS + c] = (clock64() << 3) | (id); \
             *cnt = c + 1;                                                                  \
@@ -26,14 +29,14 @@ struct Layer { const float4* wp; const float* bias; int kblocks, ntiles, tpw; };
 struct Args { Layer L[4]; int nlayers; int ld0, ld1; float* y; long long* probe; int mix; };
 
 template <int RB>
-__global__ __launch_bounds__(512) void kern(Args a) {
+__global__ __launch_bounds__(PNW * 64) void kern(Args a) {
     __shared__ __attribute__((aligned(16))) float smem[39000];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     constexpr int BM = 16 * RB;
     float* in = smem;
     float* out = smem + BM * a.ld0;
-    if (tid < 8) reinterpret_cast<int*>(s_probe_dyn + 8 * PROBE_SLOTS)[tid] = 0;
-    for (int i = tid; i < BM * a.ld0; i += 512) in[i] = (float)(i % 13) * 0.01f;
+    if (tid < PNW) reinterpret_cast<int*>(s_probe_dyn + PNW * PROBE_SLOTS)[tid] = 0;
+    for (int i = tid; i < BM * a.ld0; i += PNW * 64) in[i] = (float)(i % 13) * 0.01f;
     __syncthreads();
     int ld_in = a.ld0, ld_out = a.ld1;
 #ifdef STATIC_CHAIN
@@ -46,11 +49,17 @@ __global__ __launch_bounds__(512) void kern(Args a) {
         auto fin = [=](int row, int col, float4 v) { *reinterpret_cast<float4*>(y + ((size_t)blockIdx.x * BM + row) * 256 + (col & 255)) = v; };
         float* bufB = out + BM * a.ld1;
         if constexpr (RB == 4) {
-            if (a.mix) chain_static<4, 8, 2, 2, 0, true>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
-            else chain_static<4, 8, 2, 2, 0>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
+            constexpr int T = PNW == 8 ? 2 : 1;
+            if (a.mix) chain_static<4, PNW, T, T, 0, true>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
+            else chain_static<4, PNW, T, T, 0>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
         } else if constexpr (RB == 1) {
-            if (a.L[0].tpw == 4) chain_static<1, 8, 4, 4, 2>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
-            else chain_static<1, 8, 2, 2, 1>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
+            if constexpr (PNW == 8) {
+                if (a.L[0].tpw == 4) chain_static<1, 8, 4, 4, 2>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
+                else chain_static<1, 8, 2, 2, 1>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
+            } else {
+                if (a.L[0].tpw == 2) chain_static<1, 16, 2, 2, 1>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
+                else chain_static<1, 16, 1, 1, 1>(S0, S1, S2, in, a.ld0, out, a.ld1, bufB, a.ld1, wv, lane, fin, false);
+            }
         }
         DSAT_PROBE(2);
         __syncthreads();
@@ -62,11 +71,11 @@ __global__ __launch_bounds__(512) void kern(Args a) {
         float* o = out;
         const int ld = ld_out;
 #ifdef SYNC_IN
-        dense_layer<RB, 8>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
+        dense_layer<RB, PNW>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
                            [=](int row, int col, float4 v) { *reinterpret_cast<float4*>(o + row * ld + col) = v; }, l > 0);
         DSAT_PROBE(2);
 #else
-        dense_layer<RB, 8>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
+        dense_layer<RB, PNW>(in, ld_in, L.kblocks, L.wp, L.bias, L.ntiles, L.tpw, 1, wave, lane,
                            [=](int row, int col, float4 v) { *reinterpret_cast<float4*>(o + row * ld + col) = v; });
         DSAT_PROBE(2);
         __syncthreads();
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(512) void kern(Args a) {
     __syncthreads();
     if (tid < 64 && blockIdx.x == 0) a.y[tid] += in[tid];
     __syncthreads();
-    for (int i = tid; i < 8 * PROBE_SLOTS; i += 512) a.probe[(size_t)blockIdx.x * 8 * PROBE_SLOTS + i] = s_probe_dyn[i];
+    for (int i = tid; i < PNW * PROBE_SLOTS; i += PNW * 64) a.probe[(size_t)blockIdx.x * PNW * PROBE_SLOTS + i] = s_probe_dyn[i];
 }
 
 int main(int argc, char** argv) {
@@ -111,23 +120,23 @@ int main(int argc, char** argv) {
         (void)hipMalloc(&wp, w.size() * 4); (void)hipMalloc(&bias, b.size() * 4);
         (void)hipMemcpy(wp, w.data(), w.size() * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy(bias, b.data(), b.size() * 4, hipMemcpyHostToDevice);
-        a.L[l] = Layer{wp, bias, kb, nt, pick_tpw(nt, 8, max_tpw_for_rb(rb))};
+        a.L[l] = Layer{wp, bias, kb, nt, pick_tpw(nt, PNW, PNW == 16 ? 2 : max_tpw_for_rb(rb))};
     }
     (void)hipMalloc(&a.y, ((size_t)blocks * 16 * rb * 256 + 128) * 4);
     a.mix = getenv("MIX") != nullptr;
     long long* probe;
-    const size_t np = (size_t)blocks * 8 * PROBE_SLOTS;
+    const size_t np = (size_t)blocks * PNW * PROBE_SLOTS;
     (void)hipMalloc(&probe, np * 8);
     (void)hipMemset(probe, 0, np * 8);
     a.probe = probe;
-    const size_t dyn = (8 * PROBE_SLOTS + 8) * 8;
+    const size_t dyn = (PNW * PROBE_SLOTS + PNW) * 8;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0, 0);
-        if (rb == 1) hipLaunchKernelGGL(kern<1>, dim3(blocks), dim3(512), dyn, 0, a);
-        else if (rb == 2) hipLaunchKernelGGL(kern<2>, dim3(blocks), dim3(512), dyn, 0, a);
-        else hipLaunchKernelGGL(kern<4>, dim3(blocks), dim3(512), dyn, 0, a);
+        if (rb == 1) hipLaunchKernelGGL(kern<1>, dim3(blocks), dim3(PNW * 64), dyn, 0, a);
+        else if (rb == 2) hipLaunchKernelGGL(kern<2>, dim3(blocks), dim3(PNW * 64), dyn, 0, a);
+        else hipLaunchKernelGGL(kern<4>, dim3(blocks), dim3(PNW * 64), dyn, 0, a);
         (void)hipEventRecord(e1, 0);
         (void)hipDeviceSynchronize();
         (void)hipEventElapsedTime(&ms, e0, e1);
@@ -143,8 +152,8 @@ int main(int argc, char** argv) {
                dims[l + 1], nt, tpw, kb * 4 * rb * std::min(per_simd_tiles, 2 * tpw * 1) * 32);
         std::vector<double> d[6];
         for (int b = 0; b < blocks; ++b)
-            for (int w = 0; w < 8; ++w) {
-                const long long* rec = &h[((size_t)b * 8 + w) * PROBE_SLOTS];
+            for (int w = 0; w < PNW; ++w) {
+                const long long* rec = &h[((size_t)b * PNW + w) * PROBE_SLOTS];
                 // walk the records: a layer ends with id 3
                 int li = 0;
                 long long s[8] = {0};
