@@ -208,8 +208,11 @@ def main():
             steps_prof = 2
             all_us = sum(v["avg_us"] * v["launches"] for v in prof.values()) / steps_prof
             # algorithmic flops per launch of each fused round kernel (SURVEY.md §8d per-row MACs)
+            # P1 runs R+1 times per step: rounds 0..R-1 carry query + lit, rounds 1..R carry the output MLP
+            # of the previous round (the last launch is that tail alone) -> average over the R+1 launches
+            r_ = args.rounds
             per_launch = {
-                "round_p1_var_query_lit": 2.0 * n * (40_545 + 463_360 + 17_408),   # query + lit + output MLPs
+                "round_p1_var_query_lit": 2.0 * n * (r_ * (40_545 + 463_360) + r_ * 17_408) / (r_ + 1),
                 "round_p2_clause": 2.0 * c * 130_560,                               # clause MLP
                 "round_p3_var_update": 2.0 * n * 202_170,                           # update gate
             }
