@@ -256,6 +256,43 @@ def main():
                     "share_of_device_time": gemm_us / all_us}
             result["kernel_time_us_per_step"] = {k: v["avg_us"] * v["launches"] / steps_prof
                                                  for k, v in prof.items() if v["launches"]}
+        if world == 1 and not args.no_profile and "roofline_kernels" in result:
+            # The sparse half-rounds run inside P2 / P3: their duration comes from in-kernel clock stamps
+            # (a diagnostic session, DSAT_STAMPS=1), converted with the clock the same kernels ran at
+            # (stamped tile cycles / event duration).  Bytes: SURVEY.md §8d unique-traffic model.
+            try:
+                import ctypes as C
+                from diffusionsat_amd import _lib
+                os.environ["DSAT_STAMPS"] = "1"
+                s3 = runtime.Session(graph, wts, max_rounds=args.rounds, device=dev)
+                os.environ.pop("DSAT_STAMPS", None)
+                s3.set_graph_replay(False)
+                s3.sample(1, args.rounds, seed=9, early_exit=True, want_solved_fraction=False)
+                torch.cuda.synchronize()
+                buf = (C.c_int64 * (3 * 4096 * 8))()
+                _lib.check(_lib.load().dsat_session_read_stamps(s3.handle, buf, 3 * 4096 * 8))
+                st = np.frombuffer(buf, dtype=np.int64).reshape(3, 4096, 8)
+                t2 = st[1, :(c + 63) // 64].astype(np.float64)
+                t3 = st[2, :(n + 15) // 16].astype(np.float64)
+                g2, tot2 = np.median(t2[:, 2] - t2[:, 1]), np.median(t2[:, 4] - t2[:, 0])
+                g3, tot3 = np.median(t3[:, 1] - t3[:, 0]), np.median(t3[:, 3] - t3[:, 0])
+                rk = result["roofline_kernels"]
+                us2 = g2 / tot2 * rk["round_p2_clause"]["avg_launch_us"]
+                us3 = g3 / tot3 * rk["round_p3_var_update"]["avg_launch_us"]
+                nbytes = sparse_bytes_per_round(n, c, e)
+                ach = nbytes / ((us2 + us3) * 1e-6) / 1e9
+                result["roofline_sparse"] = {
+                    "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                    "algorithmic_bytes_per_round": nbytes, "gather_us_per_round": {"p2_literal_to_clause": us2,
+                                                                                   "p3_clause_to_literal": us3},
+                    "note": "the four sparse products of a round (R3, R4, R7, R11) are the gather phases of the fused "
+                            "P2 and P3 kernels; duration = that phase's share of the tile's stamped cycles x the "
+                            "kernel's event duration; the rows are served by L2 / Infinity Cache (state written by the "
+                            "previous kernel), so this is the sparse phases' rate against the HBM roofline, not HBM "
+                            "traffic (see roofline.traffic for that)"}
+                del s3
+            except Exception as ex:      # diagnostics only: never fail the bench line
+                result["roofline_sparse"] = {"error": str(ex)}
         if world == 1 and nflight == 1 and not args.no_profile and args.steps % 2 == 0:
             # secondary figure, same run: two independent config-2 batches in flight on two HIP streams
             # (what samples(n) can do when n needs more than one batch); never the headline `value`
