@@ -268,3 +268,41 @@ def test_diffusion_step_self_conditioning(rt):
         out = s.diffusion_step(0.4, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds,
                                early_exit=False, want_logits=True, denoised=_dev(den.reshape(-1)))
         _close(out["logits"].cpu().numpy(), ref["logits"], 0, LOGIT_TOL)
+
+
+def test_facade_predict_step_and_self_conditioning(rt):
+    """QuerySAT.predict_step (model/query_sat.py:419-451, prediction_tries == 1) with its host draws
+    and the device Philox normals reproduced on the oracle side, and QuerySAT.diffusion_step_self
+    (:483-498) through the facade."""
+    from diffusionsat_amd.query_sat import GraphInputs, QuerySAT
+    from oracle import philox
+    _, batch, data = make_all("3sat")
+    ws = oracle_weights(4)
+    R, seed = 8, 5
+    model = QuerySAT(optimizer=None, test_rounds=R, seed=seed)
+    model.set_weights(ws)
+    gi = GraphInputs(batch)
+    out = model.predict_step(gi)
+    assert set(out) == {"steps_taken", "loss", "prediction"}
+    n = batch.n_vars
+    rng = np.random.default_rng(seed + 7919 * 1)                 # the draws of predict_step's first call
+    noise_scale = float(rng.random())
+    labels = rng.integers(0, 2, n).astype(np.int32)
+    one_hot = np.stack([1 - labels, labels], axis=1).astype(np.float32)
+    t = np.float32(noise_scale) ** np.float32(0.5)
+    num_at_t = one_hot * (1 - t) + t / 2
+    rounded = np.floor(num_at_t[:, 0:1] + rng.random((n, 1)).astype(np.float32))
+    noisy = np.concatenate([rounded, 1 - rounded], axis=1).astype(np.float32)
+    normal = philox.normal(seed, 1, R, n)                        # step_index = call counter
+    ref = O.diffusion_step(ws, data, np.float32(noise_scale), noisy, normal, labels, R, early_exit=True,
+                           dt=np.float32)
+    assert int(out["steps_taken"].item()) == ref["steps_taken"]
+    _close(out["prediction"].cpu().numpy(), ref["prediction"], 0, 5e-4)
+    # self-conditioning through the facade == the oracle with denoised_num
+    d = draws(n, R, seed=3)
+    den = np.random.default_rng(1).random((n, 1)).astype(np.float32)
+    out2 = model.diffusion_step_self(gi, None, None, None, 0.3, _dev(noisy), _dev(den), normal=_dev(d["normal"]),
+                                     labels=_dev(d["labels"]))
+    ref2 = O.diffusion_step(ws, data, np.float32(0.3), noisy, d["normal"], d["labels"], R, early_exit=True,
+                            dt=np.float32, denoised_num=den)
+    _close(out2["prediction"].cpu().numpy(), ref2["prediction"], 0, 5e-4)
