@@ -28,7 +28,8 @@ constexpr int NT = ROUND_NWAVES * 64;
 // Phase stamps for the diagnostic build of a session (never read by any kernel).
 #define DSAT_STAMP(a, k)                                                                  \
     do {                                                                                  \
-        if ((a).stamps != nullptr && threadIdx.x == 0) (a).stamps[blockIdx.x * 8 + (k)] = clock64(); \
+        if ((a).stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096)                 \
+            (a).stamps[blockIdx.x * 8 + (k)] = clock64();                                   \
     } while (0)
 constexpr int LDS_FLOATS = 40960;   // 160 KiB static (see kernels_chain.hip on dynamic LDS)
 
