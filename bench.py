@@ -168,6 +168,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run(nflight, seed=0)       # untimed: first-use work (hipGraph capture, allocations) whatever W is
     if args.warmup > 0:
         run(args.warmup, seed=1)
     barrier()
