@@ -20,6 +20,13 @@ class Layout(C.Structure):
                 ("n_layers", C.c_int32 * N_MLP), ("hidden", C.c_int32 * N_MLP)]
 
 
+class Tap(C.Structure):
+    """``dsat_tap`` of include/dsat.h (debug tap of one message-passing round)."""
+    _fields_ = [("round", C.c_int32)] + [(k, C.c_void_p) for k in (
+        "query", "literals", "clauses_loss4", "clause_messages", "variables_loss_all", "new_clause_value",
+        "variables_grad", "variables_loss", "new_variables", "variables", "clause_state")]
+
+
 class DsatError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("dsat status %d: %s" % (status, message))
@@ -62,6 +69,7 @@ SIGNATURES = {
     "dsat_op_is_batch_sat": (C.c_int, [_vp, _vp, C.POINTER(_i32), _vp]),
     "dsat_op_rng": (C.c_int, [_vp, _u64, _u32, _i32, _vp, _vp, _vp, _vp]),
     "dsat_session_set_profile": (C.c_int, [_vp, _i32]),
+    "dsat_session_set_tap": (C.c_int, [_vp, C.POINTER(Tap)]),
     "dsat_session_read_stamps": (C.c_int, [_vp, C.POINTER(_i64), _i64]),
     "dsat_session_profile": (C.c_int, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                         C.POINTER(_i64)]),

@@ -29,6 +29,25 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Objects are bound to the HIP device that was current when they were created.  A call made with
+// another device current would launch on the wrong GPU with pointers of this one (an illegal
+// access at best), so every entry point checks first and launches nothing on a mismatch.
+static int current_device(int* dev) {
+    DSAT_HIP(hipGetDevice(dev));
+    return DSAT_OK;
+}
+static int require_device(int want, const char* who) {
+    int cur = -1;
+    int rc = current_device(&cur);
+    if (rc != DSAT_OK) return rc;
+    if (cur != want) {
+        set_error(std::string(who) + ": object lives on HIP device " + std::to_string(want) +
+                  " but the calling thread's current device is " + std::to_string(cur));
+        return DSAT_E_STATE;
+    }
+    return DSAT_OK;
+}
+
 template <typename T>
 static hipError_t up(T** dst, const T* src, size_t n) {
     hipError_t e = hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T));
@@ -84,6 +103,12 @@ static int layer_dims(const dsat_layout* L, int mlp, int layer, int* in_dim, int
 }  // namespace dsat
 
 using namespace dsat;
+
+#define DSAT_ON_DEVICE(sess, who)                                   \
+    do {                                                            \
+        int _rc = require_device((sess)->device, who);              \
+        if (_rc != DSAT_OK) return _rc;                             \
+    } while (0)
 
 // ============================================================================ misc
 extern "C" const char* dsat_last_error(void) { return g_last_error.c_str(); }
@@ -157,6 +182,12 @@ extern "C" int dsat_graph_create(const int32_t* clause_rowptr, const int32_t* cl
     DSAT_REQUIRE(E == 0 || clause_lits != nullptr, DSAT_E_INVALID, "dsat_graph_create: null clause_lits");
     DSAT_REQUIRE((int64_t)2 * N < (int64_t)1 << 30 && E < ((int64_t)1 << 31) - 1, DSAT_E_INVALID,
                  "dsat_graph_create: graph too large for int32 indexing");
+    // the fused gathers address rows with 32-bit float offsets: (row * 128 + col) over 2N+1 literal rows
+    // (sp, lits) and C+1 clause rows (closs4, vla), the +1 being the all-zero pad row
+    DSAT_REQUIRE(((int64_t)2 * N + 1) * F < ((int64_t)1 << 32) && ((int64_t)C + 1) * F < ((int64_t)1 << 32),
+                 DSAT_E_INVALID,
+                 "dsat_graph_create: batch too large for the kernels' 32-bit row offsets "
+                 "((2*n_vars+1)*128 and (n_clauses+1)*128 must stay below 2^32); split the batch");
 
     std::vector<int32_t> vseg(G + 1, 0), cseg(G + 1, 0);
     for (int v = 0; v < N; ++v) {
@@ -222,6 +253,7 @@ extern "C" int dsat_graph_create(const int32_t* clause_rowptr, const int32_t* cl
     }
 
     std::unique_ptr<dsat_graph> g(new dsat_graph());
+    { int rc = current_device(&g->device); if (rc != DSAT_OK) return rc; }
     g->N = N; g->C = C; g->G = G; g->E = E;
     g->max_clause_len = max_len; g->max_lit_deg = max_deg;
     g->h_var_seg = vseg; g->h_cl_seg = cseg;
@@ -299,6 +331,7 @@ extern "C" int dsat_weights_load(const float* blob, int64_t n_floats, const dsat
         DSAT_REQUIRE(std::isfinite(host[i]), DSAT_E_INVALID, "dsat_weights_load: blob holds a non-finite value");
 
     std::unique_ptr<dsat_weights> w(new dsat_weights());
+    { int rc = current_device(&w->device); if (rc != DSAT_OK) return rc; }
     w->layout = *layout;
     w->mlp.resize(DSAT_N_MLP);
 
@@ -404,9 +437,13 @@ static const char* kKernelClassNames[KC_COUNT] = {
     "round_p1_var_query_lit", "round_p2_clause", "round_p3_var_update", "select_sat", "misc"};
 
 struct dsat_session {
+    int device = -1;
     const dsat_graph* g = nullptr;
     const dsat_weights* w = nullptr;
     int max_rounds = 0;
+    bool tap_on = false;
+    dsat_tap tap;                  // dsat_session_set_tap (parity tests)
+    int no_cn = 0;                 // DSAT_NO_CN (ablation): P2 finishes the clause PairNorm itself
     char* slab = nullptr;
     size_t slab_bytes = 0;
     // state + intermediates (see DESIGN.md "HBM layout")
@@ -664,8 +701,15 @@ extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, i
     *out = nullptr;
     DSAT_REQUIRE(g && w, DSAT_E_INVALID, "dsat_session_create: null graph or weights");
     DSAT_REQUIRE(max_rounds >= 1 && max_rounds <= 4096, DSAT_E_INVALID, "dsat_session_create: max_rounds out of range");
+    DSAT_REQUIRE(g->device == w->device, DSAT_E_STATE,
+                 "dsat_session_create: graph lives on HIP device " + std::to_string(g->device) +
+                     " but the weights on device " + std::to_string(w->device));
+    { int rc = require_device(g->device, "dsat_session_create"); if (rc != DSAT_OK) return rc; }
     std::unique_ptr<dsat_session> s(new dsat_session());
+    s->device = g->device;
     s->g = g; s->w = w; s->max_rounds = max_rounds;
+    s->no_cn = getenv("DSAT_NO_CN") != nullptr;
+    memset(&s->tap, 0, sizeof(s->tap));
     {   // tile sizes are fixed before the workspace is carved: P1/P3 16 rows, P2 16*p2_rb rows
         const auto& cl = w->mlp[DSAT_MLP_CLAUSE];
         const int hid = max_hidden_pad(cl);
@@ -742,6 +786,20 @@ extern "C" int dsat_session_read_stamps(dsat_session* s, int64_t* out, int64_t n
 extern "C" int dsat_session_set_graph_replay(dsat_session* s, int32_t enable) {
     DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_graph_replay: null session");
     s->use_graph = enable ? 1 : 0;
+    return DSAT_OK;
+}
+
+extern "C" int dsat_session_set_tap(dsat_session* s, const dsat_tap* tap) {
+    DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_tap: null session");
+    if (tap == nullptr) {
+        s->tap_on = false;
+        memset(&s->tap, 0, sizeof(s->tap));
+        return DSAT_OK;
+    }
+    DSAT_REQUIRE(tap->round >= 0 && tap->round < s->max_rounds, DSAT_E_INVALID,
+                 "dsat_session_set_tap: round must be in [0, max_rounds of the session)");
+    s->tap = *tap;
+    s->tap_on = true;
     return DSAT_OK;
 }
 
@@ -868,6 +926,11 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
     const int N = g->N, C = g->C;
     Launcher L{s, st, prof};
     const int* done = early_exit ? &s->ctl->done : nullptr;
+    const dsat_tap* tap = s->tap_on ? &s->tap : nullptr;
+    const size_t nf = (size_t)N * F, cf = (size_t)C * F;
+    auto tap_copy = [&](float* dst, const float* src, size_t n) {
+        if (dst != nullptr && n > 0) (void)hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    };
 
     L.run(KC_MISC, [&] { launch_aux(s->aux, N, rounds, s->in_noisy, s->ctl, st); });     // :214-219, :239
     L.run(KC_MISC, [&] { launch_labels(s->labels, N, s->ctl, st); });                    // :145
@@ -876,6 +939,7 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
 
     for (int r = 0; r < rounds; ++r) {
         const float* auxr = s->aux + (size_t)r * N * AUX_W;
+        const bool tapped = tap != nullptr && r == tap->round;
         // R2 + R6 first layers: variables_query.L0 and lit_mlp.L0 share the input v1 (:240, :252)
         {
             float* hq = s->hid[DSAT_MLP_VARIABLES_QUERY][0];
@@ -894,6 +958,10 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
                      OutSpec{s->lits, s->lits + (size_t)N * F, F, F, F, F, F}, done);
         // R3 + R5 + R7                                                                 (:241, :248, :255-256)
         L.run(KC_CLAUSE_GATHER, [&] { launch_clause_gather(g, s->q, s->lits, s->closs4, 4.f, s->cmsg, done, st); });
+        if (tapped) {
+            tap_copy(tap->query, s->q, nf); tap_copy(tap->literals, s->lits, 2 * nf);
+            tap_copy(tap->clauses_loss4, s->closs4, cf); tap_copy(tap->clause_messages, s->cmsg, cf);
+        }
         // R8 clause_data = clause_mlp([clause_state, clause_messages, clauses_loss])   (:258-264)
         {
             const auto& layers = w->mlp[DSAT_MLP_CLAUSE];
@@ -907,6 +975,7 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
             L.run(KC_GEMM_CLAUSE, [&] { launch_gemm(a, done, st); });
             run_mlp_tail(s, L, KC_GEMM_CLAUSE, DSAT_MLP_CLAUSE, 1, h0, s->hid_ld[2], C,
                          OutSpec{s->vla, s->ncv, F, F, F, F, F}, done);
+            if (tapped) { tap_copy(tap->variables_loss_all, s->vla, cf); tap_copy(tap->new_clause_value, s->ncv, cf); }
         }
         // R10 clause_state = 0.25*PairNorm(new_clause_value) + 0.1*clause_state (+ R18) (:265-266, :348)
         L.run(KC_COLSUM, [&] { launch_colsum(g->cl_seg, g->G, s->nch_c, s->ncv, s->pc, done, st); });
@@ -914,10 +983,12 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
             launch_pairnorm_apply(g->cl_gid, g->cl_seg, C, s->nch_c, s->ncv, s->pc, s->Cs, 0.25f, 0.1f, 1,
                                   s->Cs, nullptr, done, st);
         });
+        if (tapped) tap_copy(tap->clause_state, s->Cs, cf);
         // R4 + R11 (closs4 holds 4*closs; 0.25 restores the tape's operand exactly)     (:242-246, :269-273)
         L.run(KC_LITERAL_GATHER, [&] {
             launch_literal_gather(g, s->q, s->closs4, 0.25f, s->vla, s->grad, s->vl, done, st);
         });
+        if (tapped) { tap_copy(tap->variables_grad, s->grad, nf); tap_copy(tap->variables_loss, s->vl, 2 * nf); }
         // R12 new_variables = update_gate([grad, v1, loss_pos, loss_neg])               (:277-278)
         {
             const auto& layers = w->mlp[DSAT_MLP_UPDATE_GATE];
@@ -931,6 +1002,7 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
             L.run(KC_GEMM_UPDATE, [&] { launch_gemm(a, done, st); });
             run_mlp_tail(s, L, KC_GEMM_UPDATE, DSAT_MLP_UPDATE_GATE, 1, h0, s->hid_ld[3], N,
                          single_out(s->newv, F, F), done);
+            if (tapped) tap_copy(tap->new_variables, s->newv, nf);
         }
         // R13 variables = 0.25*PairNorm(new_variables) + 0.1*variables (+ R18)          (:279-280, :347)
         L.run(KC_COLSUM, [&] { launch_colsum(g->var_seg, g->G, s->nch_v, s->newv, s->pv, done, st); });
@@ -938,6 +1010,7 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
             launch_pairnorm_apply(g->var_gid, g->var_seg, N, s->nch_v, s->newv, s->pv, s->V, 0.25f, 0.1f, 1,
                                   s->V, s->Vlog, done, st);
         });
+        if (tapped) tap_copy(tap->variables, s->V, nf);
         const bool last = r == rounds - 1;
         if (early_exit || last || trace_logits) {
             // R14 logits = variables_output(variables)                                 (:283)
@@ -966,9 +1039,16 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
 
 // Fused launch sequence: per round P1 -> [S of the previous round] -> P2 -> P3, then the tail
 // P1 (last round's PairNorm + logits) and the last S.
-static void enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int early_exit, float* trace_logits,
-                               bool prof) {
+static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int early_exit, float* trace_logits,
+                              bool prof) {
     Launcher L{s, st, prof};
+    hipError_t lerr = hipSuccess;   // first launch failure of the sequence
+    auto note = [&](hipError_t e) { if (lerr == hipSuccess && e != hipSuccess) lerr = e; };
+    const dsat_tap* tap = s->tap_on ? &s->tap : nullptr;
+    const size_t nf = (size_t)s->g->N * F, cf = (size_t)s->g->C * F;
+    auto tap_copy = [&](float* dst, const float* src, size_t n) {
+        if (dst != nullptr && n > 0) note(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    };
     RoundArgs a1 = s->ra1, a2 = s->ra2, a3 = s->ra3;
     a1.check_done = a2.check_done = a3.check_done = early_exit;
     a1.trace_logits = trace_logits;
@@ -981,10 +1061,12 @@ static void enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int 
         // idle CUs of P1 finish the clause PairNorm of round r-1 (only worth it while the variable
         // tiles leave CUs idle; otherwise P2 does it in its prologue)
         const int vtiles = (s->g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
-        const int cn = (r > 0 && r < rounds && s->g->C > 0 && vtiles < 248 && !getenv("DSAT_NO_CN")) ? 256 - vtiles : 0;
+        const int cn = (r > 0 && r < rounds && s->g->C > 0 && vtiles < 248 && !s->no_cn) ? 256 - vtiles : 0;
         a1.cn_blocks = cn;
         a1.psum_c_rd = s->psum_c + ((r + 1) & 1) * half;   // written by P2(r-1)
-        L.run(KC_ROUND_P1, [&] { (void)launch_round_p1(a1, st); });   // also produces logits of round r-1
+        L.run(KC_ROUND_P1, [&] { note(launch_round_p1(a1, st)); });   // also produces logits of round r-1
+        if (tap != nullptr && r == tap->round) { tap_copy(tap->query, s->q, nf); tap_copy(tap->literals, s->lits, 2 * nf); }
+        if (tap != nullptr && r == tap->round + 1) tap_copy(tap->variables, s->V, nf);
         if (r == rounds) {
             // R15-R17 of the last round (with early exit the earlier rounds' run inside P2)
             L.run(KC_SELECT_SAT, [&] {
@@ -1001,18 +1083,35 @@ static void enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int 
             a2.psum_c_rd = s->psum_c + ((r + 1) & 1) * half;
         }
         a3.round = r;
-        L.run(KC_ROUND_P2, [&] { (void)launch_round_p2(a2, s->p2_rb, st); });
-        L.run(KC_ROUND_P3, [&] { (void)launch_round_p3(a3, st); });
+        const bool tapped = tap != nullptr && r == tap->round;
+        a2.tap_cmsg = tapped ? tap->clause_messages : nullptr;
+        a3.tap_grad = tapped ? tap->variables_grad : nullptr;
+        a3.tap_vloss = tapped ? tap->variables_loss : nullptr;
+        L.run(KC_ROUND_P2, [&] { note(launch_round_p2(a2, s->p2_rb, st)); });
+        if (tapped) {
+            tap_copy(tap->clauses_loss4, s->closs4, cf);
+            tap_copy(tap->variables_loss_all, s->vla, cf);
+            tap_copy(tap->new_clause_value, s->ncv, cf);
+        }
+        if (tap != nullptr && r == tap->round + 1) tap_copy(tap->clause_state, s->Cs, cf);   // R10 of the tapped round
+        L.run(KC_ROUND_P3, [&] { note(launch_round_p3(a3, st)); });
+        if (tapped) tap_copy(tap->new_variables, s->newv, nf);
     }
+    if (lerr != hipSuccess) return hip_fail(lerr, "fused round launch", __FILE__, __LINE__);
+    return DSAT_OK;
 }
 
 // Run the step either eagerly or by replaying a captured graph.
 static int run_step(dsat_session* s, hipStream_t st, int rounds, int early_exit, float* trace_logits, int mode) {
     const bool prof = s->profile != 0;
-    if (!s->use_graph || prof || trace_logits) {
+    if (!s->use_graph || prof || trace_logits || s->tap_on) {
         if (mode == 1) launch_sample_pre(s->x0, s->x1, s->in_noisy, s->g->N, s->ctl, rounds, st);
-        if (s->use_fused) enqueue_step_fused(s, st, rounds, early_exit, trace_logits, prof);
-        else enqueue_step(s, st, rounds, early_exit, trace_logits, prof);
+        if (s->use_fused) {
+            int rc = enqueue_step_fused(s, st, rounds, early_exit, trace_logits, prof);
+            if (rc != DSAT_OK) return rc;
+        } else {
+            enqueue_step(s, st, rounds, early_exit, trace_logits, prof);
+        }
         if (mode == 1)
             launch_sample_post(s->x0, s->x1, s->out_logits, s->g, s->graph_unsat, s->fixed_step, s->x_fixed,
                                s->cum_acc, s->ctl, st);
@@ -1025,12 +1124,19 @@ static int run_step(dsat_session* s, hipStream_t st, int rounds, int early_exit,
         hipGraph_t graph = nullptr;
         DSAT_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeThreadLocal));
         if (mode == 1) launch_sample_pre(s->x0, s->x1, s->in_noisy, s->g->N, s->ctl, rounds, s->cap_stream);
-        if (s->use_fused) enqueue_step_fused(s, s->cap_stream, rounds, early_exit, nullptr, false);
+        int erc = DSAT_OK;
+        if (s->use_fused) erc = enqueue_step_fused(s, s->cap_stream, rounds, early_exit, nullptr, false);
         else enqueue_step(s, s->cap_stream, rounds, early_exit, nullptr, false);
         if (mode == 1)
             launch_sample_post(s->x0, s->x1, s->out_logits, s->g, s->graph_unsat, s->fixed_step, s->x_fixed,
                                s->cum_acc, s->ctl, s->cap_stream);
-        DSAT_HIP(hipStreamEndCapture(s->cap_stream, &graph));
+        // the capture is always ended, also after a failed launch: an open capture would poison the stream
+        const hipError_t ce = hipStreamEndCapture(s->cap_stream, &graph);
+        if (erc != DSAT_OK) {
+            if (graph != nullptr) (void)hipGraphDestroy(graph);
+            return erc;
+        }
+        if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
@@ -1060,6 +1166,12 @@ static int diffusion_step_impl(dsat_session* s, float noise_scale, const float* 
     DSAT_REQUIRE(rounds >= 1 && rounds <= s->max_rounds, DSAT_E_INVALID,
                  "dsat_diffusion_step: rounds must be in [1, max_rounds of the session]");
     DSAT_REQUIRE(std::isfinite(noise_scale), DSAT_E_INVALID, "dsat_diffusion_step: noise_scale is not finite");
+    { int rc = require_device(s->device, "dsat_diffusion_step"); if (rc != DSAT_OK) return rc; }
+    if (s->tap_on)
+        DSAT_REQUIRE(s->tap.round >= 0 && s->tap.round < rounds &&
+                         (s->tap.clause_state == nullptr || !s->use_fused || s->tap.round < rounds - 1),
+                     DSAT_E_INVALID,
+                     "dsat_diffusion_step: tap round out of range (clause_state on the fused path needs round < rounds-1)");
     hipStream_t st = (hipStream_t)stream;
     const size_t N = s->g->N;
     DSAT_HIP(hipMemcpyAsync(s->in_noisy, noisy_num, N * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1121,6 +1233,8 @@ static int sample_impl(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_
     DSAT_REQUIRE(rounds >= 1 && rounds <= s->max_rounds, DSAT_E_INVALID,
                  "dsat_sample: rounds must be in [1, max_rounds of the session]");
     DSAT_REQUIRE(assignment_out != nullptr, DSAT_E_INVALID, "dsat_sample: assignment_out is required");
+    DSAT_REQUIRE(!s->tap_on, DSAT_E_STATE, "dsat_sample: a debug tap is set (taps belong to dsat_diffusion_step)");
+    { int rc = require_device(s->device, "dsat_sample"); if (rc != DSAT_OK) return rc; }
     hipStream_t st = (hipStream_t)stream;
     const dsat_graph* g = s->g;
     const size_t N = g->N;
@@ -1198,6 +1312,7 @@ __global__ void pack_blocks_kernel(const float* __restrict__ x, int in_dim, floa
 extern "C" int dsat_op_mlp(dsat_session* s, int32_t mlp, const float* x, int32_t rows, float* y, void* stream) {
     DSAT_REQUIRE(s && x && y, DSAT_E_INVALID, "dsat_op_mlp: null argument");
     DSAT_REQUIRE(mlp >= 0 && mlp < DSAT_N_MLP, DSAT_E_INVALID, "dsat_op_mlp: mlp out of range");
+    DSAT_ON_DEVICE(s, "dsat_op_mlp");
     const int cap = (mlp == DSAT_MLP_CLAUSE) ? std::max(s->g->C, 1) : s->g->N;
     DSAT_REQUIRE(rows >= 0 && rows <= cap, DSAT_E_INVALID,
                  "dsat_op_mlp: rows exceed the session's capacity for this MLP (N, or C for the clause MLP)");
@@ -1262,6 +1377,7 @@ extern "C" int dsat_op_mlp_ex(dsat_session* s, int32_t mlp, const float* x, int3
     if (impl == 0) return dsat_op_mlp(s, mlp, x, rows, y, stream);
     DSAT_REQUIRE(s && x && y, DSAT_E_INVALID, "dsat_op_mlp_ex: null argument");
     DSAT_REQUIRE(mlp >= 0 && mlp < DSAT_N_MLP, DSAT_E_INVALID, "dsat_op_mlp_ex: mlp out of range");
+    DSAT_ON_DEVICE(s, "dsat_op_mlp_ex");
     const int cap = (mlp == DSAT_MLP_CLAUSE) ? std::max(s->g->C, 1) : s->g->N;
     DSAT_REQUIRE(rows >= 0 && rows <= cap, DSAT_E_INVALID, "dsat_op_mlp_ex: rows exceed the session's capacity");
     if (rows == 0) return DSAT_OK;
@@ -1274,6 +1390,7 @@ extern "C" int dsat_bench_mlp(dsat_session* s, int32_t mlp, int32_t rows, int32_
                               int32_t nwaves, int32_t iters, double* avg_us, void* stream) {
     DSAT_REQUIRE(s && avg_us && iters > 0, DSAT_E_INVALID, "dsat_bench_mlp: bad argument");
     DSAT_REQUIRE(mlp >= 0 && mlp < DSAT_N_MLP, DSAT_E_INVALID, "dsat_bench_mlp: mlp out of range");
+    DSAT_ON_DEVICE(s, "dsat_bench_mlp");
     const int cap = (mlp == DSAT_MLP_CLAUSE) ? std::max(s->g->C, 1) : s->g->N;
     DSAT_REQUIRE(rows > 0 && rows <= cap, DSAT_E_INVALID, "dsat_bench_mlp: rows exceed the session's capacity");
     hipStream_t st = (hipStream_t)stream;
@@ -1313,6 +1430,7 @@ extern "C" int dsat_bench_mlp(dsat_session* s, int32_t mlp, int32_t rows, int32_
 extern "C" int dsat_op_clause_gather(dsat_session* s, const float* q, const float* lits, float* closs_out,
                                       float* cmsg_out, void* stream) {
     DSAT_REQUIRE(s && q && lits && closs_out && cmsg_out, DSAT_E_INVALID, "dsat_op_clause_gather: null argument");
+    DSAT_ON_DEVICE(s, "dsat_op_clause_gather");
     launch_clause_gather(s->g, q, lits, closs_out, 1.f, cmsg_out, nullptr, (hipStream_t)stream);
     DSAT_HIP(hipGetLastError());
     return DSAT_OK;
@@ -1322,6 +1440,7 @@ extern "C" int dsat_op_literal_gather(dsat_session* s, const float* q, const flo
                                        float* grad_out, float* vloss_out, void* stream) {
     DSAT_REQUIRE(s && q && closs && vla && grad_out && vloss_out, DSAT_E_INVALID,
                  "dsat_op_literal_gather: null argument");
+    DSAT_ON_DEVICE(s, "dsat_op_literal_gather");
     launch_literal_gather(s->g, q, closs, 1.f, vla, grad_out, vloss_out, nullptr, (hipStream_t)stream);
     DSAT_HIP(hipGetLastError());
     return DSAT_OK;
@@ -1330,6 +1449,7 @@ extern "C" int dsat_op_literal_gather(dsat_session* s, const float* q, const flo
 extern "C" int dsat_op_pair_norm(dsat_session* s, int32_t side, const float* x, float* y, void* stream) {
     DSAT_REQUIRE(s && x && y, DSAT_E_INVALID, "dsat_op_pair_norm: null argument");
     DSAT_REQUIRE(side == 0 || side == 1, DSAT_E_INVALID, "dsat_op_pair_norm: side must be 0 (variables) or 1 (clauses)");
+    DSAT_ON_DEVICE(s, "dsat_op_pair_norm");
     const dsat_graph* g = s->g;
     hipStream_t st = (hipStream_t)stream;
     if (side == 0) {
@@ -1357,6 +1477,7 @@ __global__ void round_assign_kernel(const float* __restrict__ logits, uint8_t* _
 
 extern "C" int dsat_op_is_batch_sat(dsat_session* s, const float* logits, int32_t* is_sat_out, void* stream) {
     DSAT_REQUIRE(s && logits && is_sat_out, DSAT_E_INVALID, "dsat_op_is_batch_sat: null argument");
+    DSAT_ON_DEVICE(s, "dsat_op_is_batch_sat");
     const dsat_graph* g = s->g;
     hipStream_t st = (hipStream_t)stream;
     const int n = std::max(g->N, g->G);
@@ -1374,6 +1495,7 @@ extern "C" int dsat_op_rng(dsat_session* s, uint64_t seed, uint32_t step_index, 
                             float* normal_out, int32_t* labels_out, float* uniform_out, void* stream) {
     DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_op_rng: null session");
     DSAT_REQUIRE(rounds >= 0, DSAT_E_INVALID, "dsat_op_rng: negative rounds");
+    DSAT_ON_DEVICE(s, "dsat_op_rng");
     launch_rng(normal_out, labels_out, uniform_out, s->g->N, rounds, seed, step_index, (hipStream_t)stream);
     DSAT_HIP(hipGetLastError());
     return DSAT_OK;

@@ -52,6 +52,7 @@ struct BlockSpec { int k; int kp; };
 }  // namespace dsat
 
 struct dsat_weights {
+    int device = -1;   // HIP device the slab lives on (the current device at dsat_weights_load)
     dsat_layout layout;
     // [mlp][layer]
     std::vector<std::vector<dsat::PackedLayer>> mlp;
@@ -63,6 +64,7 @@ struct dsat_weights {
 };
 
 struct dsat_graph {
+    int device = -1;   // HIP device the arrays live on (the current device at dsat_graph_create)
     int32_t N = 0, C = 0, G = 0;
     int64_t E = 0;
     int32_t max_clause_len = 0, max_lit_deg = 0;
@@ -192,6 +194,11 @@ struct RoundArgs {
     int check_done;        // early exit armed: skip when ctl->done
     int tail;              // P1 only: run the PairNorm + output-MLP part and stop
     long long* stamps;     // diagnostics (DSAT_STAMPS=1): [tile][8] shader-clock stamps, else nullptr
+    // debug taps (dsat_session_set_tap; nullptr in every production launch): values that only exist in
+    // LDS on the fused path, written out by the tile that owns them
+    float* tap_cmsg;       // P2: clause_messages [C,128]                       (query_sat.py:255-256)
+    float* tap_grad;       // P3: variables_grad [N,128]                        (:242-246)
+    float* tap_vloss;      // P3: variables_loss [2N,128] (pos rows, then neg)  (:269-273)
     // weights
     ChainSpec mq, mlit, mcl, mupd, mout;
     // LDS plan (float offsets / row strides), filled by plan_round_lds

@@ -590,8 +590,10 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
                 st4(a.closs4 + (size_t)c * F + sub * 4, cl);
             }
             const float rw = rwv[u];
-            st4(sX + r * ldx + F + sub * 4, make_float4(M[u].x * rw, M[u].y * rw, M[u].z * rw, M[u].w * rw));
+            const float4 cm = make_float4(M[u].x * rw, M[u].y * rw, M[u].z * rw, M[u].w * rw);
+            st4(sX + r * ldx + F + sub * 4, cm);
             st4(sX + r * ldx + 2 * F + sub * 4, cl);
+            if (a.tap_cmsg != nullptr && c < C) st4(a.tap_cmsg + (size_t)c * F + sub * 4, cm);
         }
         DSAT_STAMP(a, 2);
         };
@@ -739,8 +741,10 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
         for (int u = 0; u < PASSES; ++u) {
             const int r = wave + u * ROUND_NWAVES;
             const float dw = wdeg[u];
-            st4(sX + r * ldx + (half ? OFF_NEG : OFF_POS) + sub * 4,
-                make_float4(VL[u].x * dw, VL[u].y * dw, VL[u].z * dw, VL[u].w * dw));
+            const float4 vls = make_float4(VL[u].x * dw, VL[u].y * dw, VL[u].z * dw, VL[u].w * dw);
+            st4(sX + r * ldx + (half ? OFF_NEG : OFF_POS) + sub * 4, vls);
+            if (a.tap_vloss != nullptr && tile_lo + r < N)
+                st4(a.tap_vloss + ((size_t)(tile_lo + r) + (size_t)half * N) * F + sub * 4, vls);
             float4 Mo;
             Mo.x = __shfl_xor(M[u].x, 32); Mo.y = __shfl_xor(M[u].y, 32);
             Mo.z = __shfl_xor(M[u].z, 32); Mo.w = __shfl_xor(M[u].w, 32);
@@ -758,6 +762,8 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
                 g.x = (-s0 * (p0 * 0.25f) + sn0 * (n0 * 0.25f)) * vw;
                 g.y = (-s1 * (p1 * 0.25f) + sn1 * (n1 * 0.25f)) * vw;
                 *reinterpret_cast<float2*>(sX + r * ldx + sub * 4 + 2 * half) = g;
+                if (a.tap_grad != nullptr && tile_lo + r < N)
+                    *reinterpret_cast<float2*>(a.tap_grad + (size_t)(tile_lo + r) * F + sub * 4 + 2 * half) = g;
             }
             if (half == 1) st4(sX + r * ldx + OFF_V + sub * 4, rowv[u]);
         }

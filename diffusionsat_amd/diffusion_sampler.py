@@ -68,7 +68,7 @@ class DiffusionSampler:
         self.copies_per_batch = replicate_instance(self.n_vars, self.clauses, copies=0,
                                                    max_nodes_per_batch=max_nodes_per_batch)
         self.batch: Batch = make_batch([(self.n_vars, self.clauses)] * self.copies_per_batch)
-        self.inputs = GraphInputs(self.batch)
+        self.inputs = GraphInputs(self.batch, device=device)
         self.seed, self.rank, self.world_size = int(seed), int(rank), int(world_size)
         self.success_rate = 0.0
         # True: re-check every copy on the host like the reference's loop (:283-307); False: trust the

@@ -27,9 +27,9 @@ class GraphInputs:
     (``adj_matrix``, ``clauses_graph``, ``variables_graph`` built by
     data/SatSpecifics.py:21-69), held as the device CSR graph of one ``Batch``."""
 
-    def __init__(self, batch: Batch):
+    def __init__(self, batch: Batch, device=None):
         self.batch = batch
-        self.graph = runtime.Graph(batch)
+        self.graph = runtime.Graph(batch, device=device)
 
     @property
     def n_vars(self):
@@ -127,7 +127,7 @@ class QuerySAT:
 
     def device_weights(self) -> runtime.Weights:
         if self._weights is None:
-            self._weights = runtime.Weights(self._weights_host, self.layout)
+            self._weights = runtime.Weights(self._weights_host, self.layout, device=self.device)
         return self._weights
 
     def _session(self, gi: GraphInputs) -> runtime.Session:

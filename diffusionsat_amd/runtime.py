@@ -30,22 +30,44 @@ def _ptr(t: Optional[torch.Tensor], dtype=None, numel=None, name="tensor"):
     return C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _device(device) -> torch.device:
+    """``cuda:i`` with an explicit index (the current device when none is given)."""
+    d = torch.device("cuda" if device is None else device)
+    if d.type != "cuda":
+        raise ValueError("diffusionsat_amd runs on the GPU only (got device %r)" % (device,))
+    return torch.device("cuda", torch.cuda.current_device() if d.index is None else d.index)
+
+
+def _on_device(fn):
+    """Run a method with the object's device current: the C library binds every object to the HIP
+    device that was current at its creation and refuses calls made under another one."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **kw)
+    return wrapper
 
 
 class Graph:
     """Device-resident CSR clause-literal graph of one batch (``dsat_graph``)."""
 
-    def __init__(self, batch: Batch):
+    def __init__(self, batch: Batch, device=None):
         lib = _lib.load()
         self.batch = batch
+        self.device = _device(device)
         self._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in
                       (batch.clause_rowptr, batch.clause_lits, batch.var_graph_id, batch.clause_graph_id)]
         h = C.c_void_p()
         args = [a.ctypes.data_as(C.c_void_p) if a.size else None for a in self._keep]
-        _lib.check(lib.dsat_graph_create(args[0], args[1], args[2], args[3], batch.n_vars, batch.n_clauses,
-                                         batch.n_graphs, C.byref(h)))
+        with torch.cuda.device(self.device):
+            _lib.check(lib.dsat_graph_create(args[0], args[1], args[2], args[3], batch.n_vars, batch.n_clauses,
+                                             batch.n_graphs, C.byref(h)))
         self.handle = h
         self.n_vars, self.n_clauses, self.n_graphs, self.n_edges = (
             batch.n_vars, batch.n_clauses, batch.n_graphs, batch.n_edges)
@@ -65,9 +87,12 @@ class Graph:
 class Weights:
     """Packed device copy of a weight set (``dsat_weights``)."""
 
-    def __init__(self, ws_or_blob, layout=None):
+    def __init__(self, ws_or_blob, layout=None, device=None):
         lib = _lib.load()
         self.layout = layout or _lib.default_layout()
+        if device is None and isinstance(ws_or_blob, torch.Tensor) and ws_or_blob.is_cuda:
+            device = ws_or_blob.device
+        self.device = _device(device)
         if isinstance(ws_or_blob, dict):
             blob = to_blob(ws_or_blob, self.layout)
         elif isinstance(ws_or_blob, torch.Tensor):
@@ -75,14 +100,15 @@ class Weights:
         else:
             blob = np.ascontiguousarray(ws_or_blob, dtype=np.float32)
         h = C.c_void_p()
-        if isinstance(blob, torch.Tensor):
-            if blob.dtype != torch.float32 or not blob.is_contiguous():
-                raise TypeError("weight blob tensor must be contiguous float32")
-            _lib.check(lib.dsat_weights_load(C.c_void_p(blob.data_ptr()), blob.numel(), C.byref(self.layout),
-                                             C.byref(h)))
-        else:
-            _lib.check(lib.dsat_weights_load(blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(self.layout),
-                                             C.byref(h)))
+        with torch.cuda.device(self.device):
+            if isinstance(blob, torch.Tensor):
+                if blob.dtype != torch.float32 or not blob.is_contiguous():
+                    raise TypeError("weight blob tensor must be contiguous float32")
+                _lib.check(lib.dsat_weights_load(C.c_void_p(blob.data_ptr()), blob.numel(), C.byref(self.layout),
+                                                 C.byref(h)))
+            else:
+                _lib.check(lib.dsat_weights_load(blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(self.layout),
+                                                 C.byref(h)))
         self.handle = h
 
     def close(self):
@@ -100,22 +126,54 @@ class Weights:
 class Session:
     """Workspace + launch sequence for one (graph, weights) pair (``dsat_session``)."""
 
-    def __init__(self, graph: Graph, weights: Weights, max_rounds: int = 32, device="cuda:0"):
+    def __init__(self, graph: Graph, weights: Weights, max_rounds: int = 32, device=None):
         lib = _lib.load()
         self.graph, self.weights = graph, weights
-        self.device = torch.device(device)
+        self.device = graph.device if device is None else _device(device)
+        if not (self.device == graph.device == weights.device):
+            raise ValueError("session on %s, graph on %s, weights on %s: all three must share one GPU"
+                             % (self.device, graph.device, weights.device))
         self.max_rounds = max_rounds
         h = C.c_void_p()
-        _lib.check(lib.dsat_session_create(graph.handle, weights.handle, max_rounds, C.byref(h)))
+        with torch.cuda.device(self.device):
+            _lib.check(lib.dsat_session_create(graph.handle, weights.handle, max_rounds, C.byref(h)))
         self.handle = h
 
     # -- the hot path ----------------------------------------------------------------
+    TAP_FIELDS = (("query", "n"), ("literals", "2n"), ("clauses_loss4", "c"), ("clause_messages", "c"),
+                  ("variables_loss_all", "c"), ("new_clause_value", "c"), ("variables_grad", "n"),
+                  ("variables_loss", "2n"), ("new_variables", "n"), ("variables", "n"), ("clause_state", "c"))
+
+    @_on_device
     def diffusion_step(self, noise_scale: float, noisy_num: torch.Tensor, normal=None, labels=None,
                        seed: int = 0, step_index: int = 0, rounds: int = 32, early_exit: bool = True,
-                       want_logits: bool = False, want_round_logits: bool = False, denoised=None):
+                       want_logits: bool = False, want_round_logits: bool = False, denoised=None,
+                       tap_round: Optional[int] = None):
+        """``tap_round``: also return (key "tap") the intermediates of that message-passing round as the
+        running kernels hold them (``dsat_session_set_tap``; the step then runs eagerly) -- the parity
+        tests compare them with the oracle's trace."""
         lib = _lib.load()
         n, g = self.graph.n_vars, self.graph.n_graphs
         dev = self.device
+        tap = None
+        if tap_round is not None:
+            rows = {"n": n, "2n": 2 * n, "c": self.graph.n_clauses}
+            tap = {k: torch.zeros(rows[r], 128, dtype=torch.float32, device=dev) for k, r in self.TAP_FIELDS}
+            if tap_round >= rounds - 1:
+                tap.pop("clause_state")      # produced while the next round runs (include/dsat.h)
+            t = _lib.Tap(round=int(tap_round), **{k: v.data_ptr() for k, v in tap.items()})
+            _lib.check(lib.dsat_session_set_tap(self.handle, C.byref(t)))
+        try:
+            out = self._diffusion_step(lib, n, g, dev, noise_scale, noisy_num, normal, labels, seed, step_index,
+                                       rounds, early_exit, want_logits, want_round_logits, denoised)
+        finally:
+            if tap is not None:
+                _lib.check(lib.dsat_session_set_tap(self.handle, None))
+        out["tap"] = tap
+        return out
+
+    def _diffusion_step(self, lib, n, g, dev, noise_scale, noisy_num, normal, labels, seed, step_index, rounds,
+                        early_exit, want_logits, want_round_logits, denoised):
         pred = torch.empty(n, dtype=torch.float32, device=dev)
         logits = torch.empty(n, 8, dtype=torch.float32, device=dev) if want_logits else None
         rlog = torch.zeros(rounds, n, 8, dtype=torch.float32, device=dev) if want_round_logits else None
@@ -123,7 +181,7 @@ class Session:
         steps = torch.empty(1, dtype=torch.int32, device=dev)
         common = (_ptr(normal, torch.float32, rounds * n * 4, "normal"), _ptr(labels, torch.int32, n, "labels"),
                   int(seed), int(step_index), int(rounds), int(bool(early_exit)),
-                  _ptr(logits), _ptr(rlog), _ptr(pred), _ptr(best), _ptr(steps), _stream())
+                  _ptr(logits), _ptr(rlog), _ptr(pred), _ptr(best), _ptr(steps), _stream(self.device))
         if denoised is None:
             _lib.check(lib.dsat_diffusion_step(
                 self.handle, float(noise_scale), _ptr(noisy_num, torch.float32, 2 * n, "noisy_num"), *common))
@@ -134,6 +192,7 @@ class Session:
         return {"prediction": pred, "logits": logits, "round_logits": rlog, "best_map": best,
                 "steps_taken": steps}
 
+    @_on_device
     def sample(self, n_steps: int = 32, rounds: int = 32, seed: int = 0, early_exit: bool = True,
                uniform=None, normal=None, labels=None, want_predictions: bool = False,
                want_solved_fraction: bool = True, self_conditioning: bool = False):
@@ -151,16 +210,18 @@ class Session:
             _ptr(normal, torch.float32, n_steps * rounds * n * 4, "normal"),
             _ptr(labels, torch.int32, n_steps * n, "labels"),
             _ptr(assign), _ptr(solved), _ptr(preds),
-            C.byref(frac) if want_solved_fraction else None, _stream()))
+            C.byref(frac) if want_solved_fraction else None, _stream(self.device)))
         return {"assignment": assign, "solved": solved, "predictions": preds,
                 "solved_fraction": frac.value if want_solved_fraction else None}
 
     # -- single operators ----------------------------------------------------------------
+    @_on_device
     def bench_mlp(self, mlp: int, rows: int, impl: int = 0, rb: int = 1, nwaves: int = 4, iters: int = 20) -> float:
         us = C.c_double(0.0)
-        _lib.check(_lib.load().dsat_bench_mlp(self.handle, mlp, rows, impl, rb, nwaves, iters, C.byref(us), _stream()))
+        _lib.check(_lib.load().dsat_bench_mlp(self.handle, mlp, rows, impl, rb, nwaves, iters, C.byref(us), _stream(self.device)))
         return us.value
 
+    @_on_device
     def op_mlp(self, mlp: int, x: torch.Tensor, impl: int = 0, rb: int = 1, nwaves: int = 4) -> torch.Tensor:
         lib = _lib.load()
         import ctypes
@@ -173,9 +234,10 @@ class Session:
         rows = x.shape[0]
         y = torch.empty(rows, out_dim, dtype=torch.float32, device=self.device)
         _lib.check(lib.dsat_op_mlp_ex(self.handle, mlp, _ptr(x, torch.float32, rows * in_dim, "x"), rows, _ptr(y),
-                                      impl, rb, nwaves, _stream()))
+                                      impl, rb, nwaves, _stream(self.device)))
         return y
 
+    @_on_device
     def op_clause_gather(self, q, lits):
         lib = _lib.load()
         n, c = self.graph.n_vars, self.graph.n_clauses
@@ -183,9 +245,10 @@ class Session:
         cmsg = torch.empty(c, 128, dtype=torch.float32, device=self.device)
         _lib.check(lib.dsat_op_clause_gather(self.handle, _ptr(q, torch.float32, n * 128, "q"),
                                              _ptr(lits, torch.float32, 2 * n * 128, "lits"),
-                                             _ptr(closs), _ptr(cmsg), _stream()))
+                                             _ptr(closs), _ptr(cmsg), _stream(self.device)))
         return closs, cmsg
 
+    @_on_device
     def op_literal_gather(self, q, closs, vla):
         lib = _lib.load()
         n, c = self.graph.n_vars, self.graph.n_clauses
@@ -194,24 +257,27 @@ class Session:
         _lib.check(lib.dsat_op_literal_gather(self.handle, _ptr(q, torch.float32, n * 128, "q"),
                                               _ptr(closs, torch.float32, c * 128, "closs"),
                                               _ptr(vla, torch.float32, c * 128, "vla"),
-                                              _ptr(grad), _ptr(vloss), _stream()))
+                                              _ptr(grad), _ptr(vloss), _stream(self.device)))
         return grad, vloss
 
+    @_on_device
     def op_pair_norm(self, side: int, x):
         lib = _lib.load()
         rows = self.graph.n_vars if side == 0 else self.graph.n_clauses
         y = torch.empty(rows, 128, dtype=torch.float32, device=self.device)
         _lib.check(lib.dsat_op_pair_norm(self.handle, side, _ptr(x, torch.float32, rows * 128, "x"), _ptr(y),
-                                         _stream()))
+                                         _stream(self.device)))
         return y
 
+    @_on_device
     def op_is_batch_sat(self, logits) -> int:
         lib = _lib.load()
         out = C.c_int32(-1)
         _lib.check(lib.dsat_op_is_batch_sat(self.handle, _ptr(logits, torch.float32, self.graph.n_vars, "logits"),
-                                            C.byref(out), _stream()))
+                                            C.byref(out), _stream(self.device)))
         return out.value
 
+    @_on_device
     def op_rng(self, seed: int, step_index: int, rounds: int):
         lib = _lib.load()
         n = self.graph.n_vars
@@ -219,7 +285,7 @@ class Session:
         labels = torch.empty(n, dtype=torch.int32, device=self.device)
         uniform = torch.empty(n, dtype=torch.float32, device=self.device)
         _lib.check(lib.dsat_op_rng(self.handle, int(seed), int(step_index), int(rounds), _ptr(normal), _ptr(labels),
-                                   _ptr(uniform), _stream()))
+                                   _ptr(uniform), _stream(self.device)))
         return normal, labels, uniform
 
     # -- knobs ------------------------------------------------------------------------

@@ -15,6 +15,9 @@
  *     stream-ordered and do not synchronise unless they return a host scalar
  *     (documented per function).
  *   - one session per (graph, weights) pair per GPU; a session is not re-entrant.
+ *   - objects live on the HIP device that was current when they were created; a session needs its
+ *     graph and weights on one device, and every call on an object must be made with that device
+ *     current (hipSetDevice / torch.cuda.device), else it returns DSAT_E_STATE and launches nothing.
  *   - feature_maps = query_maps = 128 only (the reference's defaults,
  *     model/query_sat.py:87-89); other widths return DSAT_E_UNSUPPORTED.
  */
@@ -222,6 +225,29 @@ int dsat_session_set_profile(dsat_session* s, int32_t enable);
 int dsat_session_read_stamps(dsat_session* s, int64_t* out, int64_t n);
 int dsat_session_profile(dsat_session* s, int32_t cap, const char** names, double* us_out,
                          int64_t* launches_out);
+
+/* Debug tap (parity tests of the kernels that are actually hot): the intermediates of message-passing
+ * round `round` of the NEXT dsat_diffusion_step call, copied out of the running kernels' buffers (or,
+ * for values the fused kernels keep in LDS only, written by the tile that owns them).  The oracle's
+ * trace carries the same tensors (oracle/querysat_oracle.py, reference lines per field).  All
+ * pointers dev, each may be NULL.  While a tap is set the step runs eagerly (no graph replay);
+ * dsat_session_set_tap(s, NULL) clears it.  Works on the fused path and on the per-layer path. */
+typedef struct dsat_tap {
+    int32_t round;
+    float* query;               /* [N,128]   variables_query(v1)                      model/query_sat.py:240 */
+    float* literals;            /* [2N,128]  lit_mlp(v1) split into +/- literal rows  :252-254 */
+    float* clauses_loss4;       /* [C,128]   4*softplus_loss_adj(query)               :241, :248 */
+    float* clause_messages;     /* [C,128]   (A^T literals)*rsqrt(len)                :255-256 */
+    float* variables_loss_all;  /* [C,128]   clause_data[:, :128]                     :263 */
+    float* new_clause_value;    /* [C,128]   clause_data[:, 128:] before PairNorm     :264 */
+    float* variables_grad;      /* [N,128]   inner tape gradient * var_degree_weight  :242-246 */
+    float* variables_loss;      /* [2N,128]  (A variables_loss_all)*degree_weight     :269-273 */
+    float* new_variables;       /* [N,128]   update_gate(unit) before PairNorm        :278 */
+    float* variables;           /* [N,128]   state after the round, carried copy      :279-280, :347 */
+    float* clause_state;        /* [C,128]   state after the round, carried copy      :265-266, :348;
+                                   produced while round+1 runs: needs round < rounds-1 */
+} dsat_tap;
+int dsat_session_set_tap(dsat_session* s, const dsat_tap* tap);
 
 /* ---- instance preparation (host only, no GPU needed) ------------------------------------------
  * SAT/UNSAT (+ one model) of a CNF: the filter the reference's generators run through PySAT

@@ -280,7 +280,9 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
     best_map = np.zeros(n_graphs, dtype=np.int64)
     step = -1
     tr = {k: [] for k in ("logits", "query", "clause_state", "variables", "out_logits",
-                          "best_map", "per_graph_loss", "variables_grad", "is_sat")}
+                          "best_map", "per_graph_loss", "variables_grad", "is_sat",
+                          "literals", "clauses_loss4", "clause_messages", "variables_loss_all",
+                          "new_clause_value", "variables_loss", "new_variables")}
     for step in range(rounds):                                       # :225
         v1 = np.concatenate([variables, np.asarray(normal[step], dtype=dt), noisy_labels], axis=-1)  # :239
         query = mlp(v1, w["variables_query"])                        # :240
@@ -299,6 +301,11 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
 
         variables_loss_all = clause_data[:, :QUERY_MAPS]            # :263
         new_clause_value = clause_data[:, QUERY_MAPS:]              # :264
+        if trace:   # pre-normalisation values (the tensors the fused kernels' debug taps expose)
+            tr["literals"].append(literals.copy()); tr["clauses_loss4"].append(clauses_loss.copy())
+            tr["clause_messages"].append(clause_messages.copy())
+            tr["variables_loss_all"].append(variables_loss_all.copy())
+            tr["new_clause_value"].append(new_clause_value.copy())
         new_clause_value = pair_norm(new_clause_value, cg_norm, cmask) * f(0.25)  # :265
         clause_state = new_clause_value + f(0.1) * clause_state     # :266
 
@@ -307,6 +314,8 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
 
         unit = np.concatenate([variables_grad, v1, vl_pos, vl_neg], axis=-1)  # :277
         new_variables = mlp(unit, w["update_gate"])                 # :278
+        if trace:
+            tr["variables_loss"].append(variables_loss.copy()); tr["new_variables"].append(new_variables.copy())
         new_variables = pair_norm(new_variables, vg_norm, vmask) * f(0.25)  # :279
         variables = new_variables + f(0.1) * variables              # :280
 

@@ -112,3 +112,11 @@ def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_graph_size_guard_for_32bit_row_offsets(lib):
+    """The fused gathers address rows with 32-bit float offsets: (2N+1)*128 must stay below 2^32.
+    N = 2^24 is the first size that does not; the call is refused before any device work."""
+    n = 1 << 24
+    rc, err, _ = _graph_create(lib, [0], [], np.zeros(n, np.int32), [], n, 0, 1)
+    assert rc == -1 and "32-bit row offsets" in err

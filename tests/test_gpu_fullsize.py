@@ -136,11 +136,14 @@ def test_facade_query_sat_and_sampler(rt, tmp_path):
     out = model.diffusion_step(gi, None, None, None, 0.5, _dev(noisy), normal=_dev(d["normal"]),
                                labels=_dev(d["labels"]))
     assert set(out) == {"steps_taken", "loss", "prediction"}
-    ref = O.diffusion_step(ws, data, np.float32(0.5), noisy, d["normal"], d["labels"], 8, dt=np.float32)
-    pgl_ok = True
+    ref = O.diffusion_step(ws, data, np.float32(0.5), noisy, d["normal"], d["labels"], 8, dt=np.float32, trace=True)
     assert out["prediction"].shape == (batch.n_vars,)
-    if np.array_equal(ref["best_map"], ref["best_map"]):
-        assert np.abs(out["prediction"].cpu().numpy() - ref["prediction"]).max() < 2e-4 or not pgl_ok
+    assert int(out["steps_taken"].item()) == ref["steps_taken"]
+    # the prediction is the selected logit map: compare on graphs whose argmin margin is clear
+    srt = np.sort(ref["trace"]["per_graph_loss"][-1], axis=1)
+    clear = ((srt[:, 1] - srt[:, 0]) > 1e-3)[data["variables_mask"]]
+    assert clear.any()
+    assert np.abs(out["prediction"].cpu().numpy() - ref["prediction"])[clear].max() < 2e-4
     x = np.random.default_rng(0).standard_normal((batch.n_vars, 128)).astype(np.float32)
     y = model.variables_output(_dev(x), gi).cpu().numpy()
     assert np.abs(y - O.mlp(x, ws["variables_output"])).max() < 1e-4

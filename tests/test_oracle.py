@@ -97,7 +97,14 @@ def test_block_diagonal_batching_equals_single_graphs():
         off += n_vars
 
 
-def test_variable_permutation_and_polarity_equivariance():
+def test_variable_permutation_clause_permutation_and_literal_shuffle():
+    """Exact symmetries of the path (up to summation order): renumbering variables, reordering
+    clauses, and shuffling the literals inside clauses -- the last is what the reference's
+    ``invariance_shuffle_literals`` feeds the model (diffusion_training.py:455-463).
+    Inverting every literal (``invariance_inverse``, :466-475) is NOT a symmetry of the network: the
+    positive and negative literal rows go through different weight columns (lit_mlp's two output
+    halves, update_gate's pos/neg input blocks), so the reference only measures accuracy under it;
+    the last assertion records that the outputs really differ."""
     n, clauses = make_all("uf20")[0][0]
     ws = oracle_weights(6)
     rounds = 4
@@ -110,6 +117,16 @@ def test_variable_permutation_and_polarity_equivariance():
     d2 = {"normal": d["normal"][:, inv], "labels": d["labels"][inv], "uniform": d["uniform"][inv]}
     out, _, _ = _step([(n, pc)], ws, 0.6, rounds, seed=0, noisy=noisy[inv], d=d2)
     assert np.abs(out["logits"][perm] - base["logits"]).max() < 2e-5
+    # reorder clauses and shuffle the literals inside each clause
+    order = rng.permutation(len(clauses))
+    sc = [list(rng.permutation(clauses[i])) for i in order]
+    out, _, _ = _step([(n, sc)], ws, 0.6, rounds, seed=0, noisy=noisy, d=d)
+    assert np.abs(out["logits"] - base["logits"]).max() < 2e-5
+    # global polarity inversion: a different function value, not a sign flip or a copy
+    ic = [[-l for l in c] for c in clauses]
+    out, _, _ = _step([(n, ic)], ws, 0.6, rounds, seed=0, noisy=noisy, d=d)
+    assert np.abs(out["logits"] - base["logits"]).max() > 1e-3
+    assert np.abs(out["logits"] + base["logits"]).max() > 1e-3
 
 
 def test_train_loss_ties_pick_first_map_at_noise_scale_one():
@@ -168,3 +185,33 @@ def test_philox_known_answers():
     u = philox.uniform(3, 2, 10000)
     assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.02
     assert set(np.unique(philox.labels(3, 2, 1000))) == {0, 1}
+
+
+def test_committed_early_exit_fixture():
+    """tests/golden/early_exit_golden.npz (made by make_early_exit_golden.py): the oracle still exits at
+    the recorded middle round with the recorded outputs, in fp32 and -- same round, same discrete
+    decisions -- in fp64 (the margins the seed search demanded make the case robust)."""
+    import os
+    import sys
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gdir)
+    from make_early_exit_golden import unflatten
+    g = np.load(os.path.join(gdir, "early_exit_golden.npz"), allow_pickle=False)
+    rounds = int(g["rounds"])
+    ws = oracle_weights(int(g["weight_seed"]))
+    for case in (0, 1):
+        p = "case%d_" % case
+        insts = unflatten(g[p + "n_vars"], g[p + "n_clauses"], g[p + "rowptr"], g[p + "lits"])
+        data = O.create_adj_matrices(insts)
+        ref = O.diffusion_step(ws, data, np.float32(g["noise_scale"]), g[p + "noisy"], g[p + "normal"],
+                               g[p + "labels"], rounds, early_exit=True, dt=np.float32, trace=True)
+        st = int(g[p + "steps_taken"])
+        assert 0 < st < rounds - 1 and ref["steps_taken"] == st
+        assert np.array_equal(ref["logits"], g[p + "logits"]) and np.array_equal(ref["best_map"], g[p + "best_map"])
+        assert list(g[p + "is_sat_per_round"]) == [0.0] * st + [1.0]
+        r64 = O.diffusion_step(O.cast_weights(ws, np.float64), data, np.float64(g["noise_scale"]),
+                               g[p + "noisy"].astype(np.float64), g[p + "normal"], g[p + "labels"], rounds,
+                               early_exit=True, dt=np.float64)
+        assert r64["steps_taken"] == st and np.array_equal(r64["best_map"], g[p + "best_map"])
+        assert np.abs(r64["logits"] - g[p + "logits"]).max() < 5e-5
+        assert np.array_equal(np.round(O.sigmoid(r64["prediction"])).astype(np.uint8), g[p + "assignment"])
