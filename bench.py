@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
 """Benchmark of the denoising-sampling hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}] [--repeats R]
 
-A "step" is one denoising step = one QuerySAT.diffusion_step of R=32 message-passing
-rounds over one 20k-node batch (BASELINE config 2: 31 distinct solver-filtered threshold 3-SAT instances,
-n=100, m=428 -> N=3100 vars, C=13268 clauses, 19468 nodes), run inside the device-side
-sampler loop (randomized rounding -> step -> SAT check -> reverse step).  Inputs are
-resident in HBM before the timed region; the step runs with the reference's semantics
-(early exit armed, per-round logits / map selection / is_batch_sat every round), which
-with random-init weights never fires, so the work per step is fixed.
+A "step" is one denoising step = one QuerySAT.diffusion_step of R=32 message-passing rounds over one
+batch, run inside the device-side sampler loop (randomized rounding -> step -> SAT check -> reverse
+step).  Inputs are resident in HBM before the timed region; the step runs with the reference's
+semantics (early exit armed, per-round logits / map selection / is_batch_sat every round), which with
+random-init weights never fires, so the work per step is fixed.
 
-For N>1 the driver launches one rank per GPU (torch.distributed.run); every rank owns
-its own batch (weak scaling), weights are broadcast from rank 0 over RCCL, and there
-is no communication in the timed region.  Rank 0 prints ONE JSON line.
+Workloads (BASELINE.json `configs`; --config, default 2 = the configuration the metric is quoted on):
+  2  31 distinct solver-filtered threshold 3-SAT instances n=100 m=428 = 19 468 nodes       (T=32)
+  3  one such instance x 256 copies = 160 768 nodes                                        (T=64)
+  4  NeuroSAT-style SR(n) mixed-width k-SAT stream, n in [30,100]: instances -> node-budget batches
+     -> per-GPU shards -> pooled sessions, host set-up of batch i+1 overlapped with batch i   (T=32)
+  5  one irregular-degree CNF of 10 000 variables / 60 000 clauses (SHA-like stand-in)      (T=128)
+
+N > 1: one process per GPU.  When the driver starts the ranks itself (torch.distributed.run sets
+WORLD_SIZE) this process is one rank; when WORLD_SIZE is unset, `--gpus N` makes THIS process the
+launcher: before anything touches a GPU it starts N fresh child processes (RANK/LOCAL_RANK/WORLD_SIZE/
+MASTER_* set), waits for them, relays rank 0's single JSON line and exits non-zero if any child
+failed.  Every rank owns its own batch (weak scaling), the weights are broadcast from rank 0 over RCCL
+and there is no communication in the timed region.
+
+The timed region (K steps between barrier + synchronize on both sides, MAX over ranks) is run
+`--repeats` times (default 5); `value` comes from the median, the line carries min/max as well.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +41,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = vector fp32 peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+DEFAULT_STEPS = {2: 32, 3: 64, 4: 32, 5: 128}     # one full sample of the config's T
 
 
 def gemm_flops_per_round(n_vars, n_clauses):
@@ -40,78 +55,156 @@ def sparse_bytes_per_round(n_vars, n_clauses, n_edges, f=128):
     return 4 * f * (7 * n_vars + 4 * n_clauses) + 16 * n_edges + 8 * (n_clauses + 1) + 8 * (2 * n_vars + 1)
 
 
-def cpu_baseline(instances, ws, rounds, budget_s=20.0):
-    """CPU restatement (oracle/querysat_torch.py), timed on this host's cores on a bounded
-    sample of the same workload: whole denoising steps of the same batch."""
+# ------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n_ranks):
+    """Launcher role: start `n_ranks` fresh python processes running this file as ranks.  Nothing here
+    touches a GPU (no torch import even), so no process that has initialised HIP is ever re-executed."""
+    env0 = dict(os.environ)
+    env0["MASTER_ADDR"] = "127.0.0.1"
+    env0["MASTER_PORT"] = str(_free_port())
+    env0["WORLD_SIZE"] = str(n_ranks)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n_ranks):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    line = ""
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if any(rcs) or not line:
+        sys.stderr.write("bench.py launcher: rank exit codes %s%s\n" % (rcs, "" if line else "; no JSON line from rank 0"))
+        return 1
+    print(line)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(instances, ws, rounds, nodes):
+    """CPU restatement (oracle/querysat_torch.py: PyTorch-CPU fp32, TensorFlow being unavailable) timed
+    on this host as SURVEY.md §8d prescribes: 1 thread and all host cores, 1 warm-up then the median
+    of 3; plus the fastest thread count of a short probe (sparse products of a 20k-node batch stop
+    scaling long before all cores of a large host are used).  Bounded sample: the first `rs` of the
+    step's `rounds` message-passing rounds (rounds cost the same), scaled to whole steps."""
     import torch
     from oracle import querysat_torch as QT
     tb = QT.TorchBatch(instances)
     tw = QT.to_torch_weights(ws)
     rng = np.random.default_rng(0)
     n = tb.n
+    rs = max(1, min(rounds, int(round(8 * 19468 / max(nodes, 1)))))
     noisy = np.stack([np.ones(n), np.zeros(n)], 1).astype(np.float32)
-    normal = rng.standard_normal((rounds, n, 4)).astype(np.float32)
+    normal = rng.standard_normal((rs, n, 4)).astype(np.float32)
     labels = rng.integers(0, 2, n)
-    with torch.no_grad():
-        QT.diffusion_step(tw, tb, 0.5, noisy, normal[:2], labels, 2)      # warm-up: 2 rounds
-        # be fair to the CPU: pick the thread count that runs this problem fastest (sparse products
-        # of a 20k-node batch stop scaling long before all cores of a large host are used)
-        ncpu = int(torch.get_num_threads())
-        best_t, best_dt = ncpu, None
-        for t in sorted({1, 4, 8, 16, 32, 64, ncpu}):
-            if t > ncpu:
-                continue
-            torch.set_num_threads(t)
-            c0 = time.perf_counter()
-            QT.diffusion_step(tw, tb, 0.5, noisy, normal[:2], labels, 2)
-            dt = time.perf_counter() - c0
-            if best_dt is None or dt < best_dt:
-                best_t, best_dt = t, dt
-        torch.set_num_threads(best_t)
-        done, t0 = 0, time.perf_counter()
-        while True:
-            QT.diffusion_step(tw, tb, 0.5, noisy, normal, labels, rounds)
-            done += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or done >= 48:
-                break
-    return {"value": done / el, "unit": "denoising-steps/s", "cores": int(torch.get_num_threads()),
-            "kind": "port",
-            "sample": "%d denoising steps (R=%d rounds) of the same config-2 batch, PyTorch-CPU fp32 restatement, "
-                      "early exit off, %.1f s; thread count chosen as the fastest of {1,4,8,16,32,64,all=%d} on a "
-                      "2-round probe" % (done, rounds, el, ncpu)}
+    ncpu = int(torch.get_num_threads())
+
+    def steps_per_s(threads, reps=3, nr=rs):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            QT.diffusion_step(tw, tb, 0.5, noisy, normal[:nr], labels, nr)          # warm-up
+            ts = []
+            for _ in range(reps):
+                c0 = time.perf_counter()
+                QT.diffusion_step(tw, tb, 0.5, noisy, normal[:nr], labels, nr)
+                ts.append(time.perf_counter() - c0)
+        med = float(np.median(ts))
+        return {"value": nr / rounds / med, "threads": threads, "seconds": [round(t, 4) for t in ts]}
+
+    t_all = time.perf_counter()
+    probe = {}
+    for t in sorted({1, 4, 8, 16, 32, 64, ncpu}):
+        if t <= ncpu:
+            probe[t] = steps_per_s(t, reps=1, nr=min(2, rs))["value"]
+    best_t = max(probe, key=probe.get)
+    one, allc, best = steps_per_s(1), steps_per_s(ncpu), steps_per_s(best_t)
+    torch.set_num_threads(ncpu)
+    return {"value": best["value"], "unit": "denoising-steps/s", "cores": best_t, "kind": "port",
+            "one_thread": one, "all_cores": allc, "best_of_probe": best, "host_cores": ncpu,
+            "sample": "the first %d of the %d message-passing rounds of one denoising step of the same batch "
+                      "(scaled to whole steps), PyTorch-CPU fp32 restatement, early exit off; 1 warm-up then "
+                      "median of 3 at 1 thread, at all %d cores and at the fastest thread count of a probe over "
+                      "{1,4,8,16,32,64,all}; %.1f s in all" % (rs, rounds, ncpu, time.perf_counter() - t_all)}
+
+
+# ------------------------------------------------------------------------------------------ workloads
+def make_workload(args, rank):
+    """Instances of this rank's batch (configs 2, 3, 5) and the workload description."""
+    from diffusionsat_amd.instances import config2_instances, config3_instances, irregular_cnf
+    if args.config == 2:
+        inst = config2_instances(args.graphs, args.vars, seed=2 + rank)
+        what = ("BASELINE config 2: %d satisfiable threshold 3-SAT instances n=%d m=%d per GPU"
+                % (len(inst), args.vars, len(inst[0][1])))
+    elif args.config == 3:
+        inst = config3_instances(args.copies, args.vars, seed=2 + rank)
+        what = ("BASELINE config 3: one satisfiable threshold 3-SAT instance n=%d m=%d x %d copies per GPU"
+                % (args.vars, len(inst[0][1]), len(inst)))
+    elif args.config == 5:
+        inst = [irregular_cnf(args.irr_vars, args.irr_clauses, seed=5 + rank, zipf_a=args.zipf)[:2]]
+        what = ("BASELINE config 5: one irregular-degree CNF per GPU (SHA-1-preimage stand-in: clause lengths 2..8 "
+                "with a heavy tail, power-law variable popularity zipf_a=%.2f), %d vars / %d clauses"
+                % (args.zipf, args.irr_vars, args.irr_clauses))
+    else:
+        raise SystemExit("unknown --config %r" % args.config)
+    return inst, what
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=None, help="timed denoising steps K (default: the config's T)")
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the K-step timed region is run")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json workload")
     ap.add_argument("--rounds", type=int, default=32)
-    ap.add_argument("--graphs", type=int, default=31, help="instances per batch (config 2: 31 x n=100)")
+    ap.add_argument("--graphs", type=int, default=31, help="config 2: instances per batch (31 x n=100)")
+    ap.add_argument("--copies", type=int, default=256, help="config 3: copies of the one instance")
     ap.add_argument("--vars", type=int, default=100)
+    ap.add_argument("--irr-vars", type=int, default=10000, help="config 5")
+    ap.add_argument("--irr-clauses", type=int, default=60000, help="config 5")
+    ap.add_argument("--zipf", type=float, default=1.3, help="config 5: popularity exponent (1.1 = heavier tail)")
+    ap.add_argument("--stream-instances", type=int, default=2048,
+                    help="config 4: instances of the stream each rank processes (the full config is 12 500 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--eager", action="store_true", help="disable hipGraph replay")
     ap.add_argument("--batches-in-flight", type=int, default=1,
-                    help="opt-in throughput mode: this many independent config-2 batches per GPU, each on its own "
-                         "HIP stream (the K steps are dealt round-robin over them); the default, 1, is the contract's "
+                    help="opt-in throughput mode: this many independent batches per GPU, each on its own HIP "
+                         "stream (the K steps are dealt round-robin over them); the default, 1, is the contract's "
                          "one batch per GPU")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = DEFAULT_STEPS[args.config]
+
+    # ---- launcher role: before any GPU / torch.cuda call ------------------------------------------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     # Rehearsal on a one-GPU box: DSAT_BENCH_BACKEND=gloo lets several ranks share cuda:0 (RCCL
     # refuses two ranks on one device); the driver's multi-GPU runs use the default, nccl = RCCL.
     backend = os.environ.get("DSAT_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
+    ndev = max(torch.cuda.device_count(), 1)
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("--gpus %d but only %d GPU(s) visible" % (world, ndev))
+    local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -123,29 +216,60 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from diffusionsat_amd import build, runtime, weights as W
+    from diffusionsat_amd import build, distributed, runtime, weights as W
     from diffusionsat_amd.batch import make_batch
-    from diffusionsat_amd.instances import config2_instances
     build.build()
 
-    # ---- inputs: one config-2 batch per rank (weak scaling), weights from rank 0 -------------
-    instances = config2_instances(args.graphs, args.vars, seed=2 + rank)
-    batch = make_batch(instances)
+    # ---- weights: rank 0's blob to every rank (RCCL over xGMI; the only collective on the path) ------
     ws = W.glorot_weights(seed=0)
     blob = torch.from_numpy(W.to_blob(ws)).to(dev)
     if dist is not None:
         if rank != 0:
             blob.zero_()
-        dist.broadcast(blob, src=0)            # RCCL over xGMI; the only collective on the path
-    graph = runtime.Graph(batch)
-    wts = runtime.Weights(blob)
+        if backend == "nccl":
+            distributed.broadcast_weight_blob(blob, src=0)
+        else:                                  # gloo rehearsal: broadcast through the host
+            hb = blob.cpu()
+            distributed.broadcast_weight_blob(hb, src=0)
+            blob.copy_(hb)
+    wts = runtime.Weights(blob, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def gather_floats(x):
+        """Every rank's value of a host float, on every rank."""
+        if dist is None:
+            return [float(x)]
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    if args.config == 4:
+        from bench_stream import run_stream_bench
+        result = run_stream_bench(args, rank, world, dev, wts, ws, barrier, gather_floats)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(result))
+        return
+
+    # ---- inputs: one batch per rank (weak scaling) -------------------------------------------------
+    instances, what = make_workload(args, rank)
+    batch = make_batch(instances)
+    graph = runtime.Graph(batch, device=dev)
     sess = runtime.Session(graph, wts, max_rounds=args.rounds, device=dev)
     sess.set_graph_replay(not args.eager)
     nflight = max(1, args.batches_in_flight)
     extra = []   # (session, stream) of the other batches in flight; each has its own instances
     for b in range(1, nflight):
-        bb = make_batch(config2_instances(args.graphs, args.vars, seed=1000 * b + 2 + rank))
-        sb = runtime.Session(runtime.Graph(bb), wts, max_rounds=args.rounds, device=dev)
+        a2 = argparse.Namespace(**vars(args))
+        bb = make_batch(make_workload(a2, 1000 * b + rank)[0])
+        sb = runtime.Session(runtime.Graph(bb, device=dev), wts, max_rounds=args.rounds, device=dev)
         sb.set_graph_replay(not args.eager)
         extra.append((sb, torch.cuda.Stream(device=dev)))
     if args.steps % nflight != 0:
@@ -163,47 +287,55 @@ def main():
             cur.wait_stream(stream)
         return out
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     run(nflight, seed=0)       # untimed: first-use work (hipGraph capture, allocations) whatever W is
     if args.warmup > 0:
         run(args.warmup, seed=1)
-    barrier()
-    t0 = time.perf_counter()
-    out = run(args.steps, seed=2)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- the timed region, `repeats` times: EXACTLY K steps between barrier + synchronize ------------
+    elapsed_all, elapsed_mine = [], []
+    out = None
+    for rep in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        out = run(args.steps, seed=2 + rep)
+        barrier()
+        el = time.perf_counter() - t0
+        elapsed_mine.append(el)
+        elapsed_all.append(max(gather_floats(el)))                  # MAX over ranks
+    elapsed = float(np.median(elapsed_all))
+    per_rank = gather_floats(args.steps / float(np.median(elapsed_mine)))
     solved_fraction = float(out["solved"].float().mean().item())
 
     result = None
     if rank == 0:
         n, c, e = batch.n_vars, batch.n_clauses, batch.n_edges
         value = world * args.steps / elapsed
+        ms = [1e3 * x / args.steps for x in elapsed_all]
+        metric = "denoising-steps/sec, 20k-node 3-SAT batch" if args.config == 2 else \
+                 "denoising-steps/sec, BASELINE config %d batch" % args.config
         result = {
-            "metric": "denoising-steps/sec, 20k-node 3-SAT batch",
+            "metric": metric,
             "value": value, "unit": "denoising-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "solved_fraction": solved_fraction,
-            "config": {"workload": "BASELINE config 2: %d satisfiable threshold 3-SAT instances n=%d m=%d per GPU "
-                                   "(N=%d vars, C=%d clauses, E=%d edges, %d nodes), R=%d rounds per denoising "
-                                   "step, T=%d steps, random-init Glorot weights, device Philox noise, early exit "
-                                   "armed (never fires)" % (batch.n_graphs, args.vars, len(instances[0][1]), n, c, e,
-                                                            batch.n_nodes, args.rounds, args.steps),
-                       "rounds": args.rounds, "nodes_per_gpu": batch.n_nodes, "parallelism": "batch-sharded x%d" % world,
-                       "hip_graph_replay": not args.eager, "batches_in_flight_per_gpu": nflight},
+            "repeats": {"n": len(ms), "ms_per_step_median": float(np.median(ms)), "ms_per_step_min": min(ms),
+                        "ms_per_step_max": max(ms), "ms_per_step_all": [round(x, 5) for x in ms],
+                        "value_min": world * args.steps / max(elapsed_all),
+                        "value_max": world * args.steps / min(elapsed_all)},
+            "per_rank_steps_per_s": [round(x, 3) for x in per_rank],
+            "config": {"workload": "%s (N=%d vars, C=%d clauses, E=%d edges, %d nodes), R=%d rounds per denoising "
+                                   "step, K=%d timed steps x %d repeats, random-init Glorot weights, device Philox "
+                                   "noise, early exit armed (never fires)"
+                                   % (what, n, c, e, batch.n_nodes, args.rounds, args.steps, len(ms)),
+                       "baseline_config": args.config, "rounds": args.rounds, "nodes_per_gpu": batch.n_nodes,
+                       "parallelism": "batch-sharded x%d" % world, "hip_graph_replay": not args.eager,
+                       "batches_in_flight_per_gpu": nflight,
+                       "max_clause_len": int(np.diff(batch.clause_rowptr).max()) if c else 0},
         }
         # ---- per-kernel device times, live (HIP events on the launch stream, eager) -------------
         if not args.no_profile:
             sess.set_profile(True)
-            run(2, seed=3)
+            run(2 * nflight, seed=3)
             prof = sess.profile()
             sess.set_profile(False)
             steps_prof = 2
@@ -220,13 +352,16 @@ def main():
             kern_name = {"round_p1_var_query_lit": "round_p1_kernel", "round_p2_clause": "round_p2_kernel<4>",
                          "round_p3_var_update": "round_p3_kernel"}
             # HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 cannot run inside
-            # this process); null when the file is absent
+            # this process); null when the file is absent or the workload is not the one it was taken on
             traffic = {}
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                    traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
-            except (OSError, KeyError, ValueError):
-                pass
+            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
+            default_cfg2 = args.config == 2 and (args.graphs, args.vars) == (31, 100)
             roofs = {}
             for k, fl in per_launch.items():
                 if k in prof and prof[k]["launches"] > 0:
@@ -234,7 +369,7 @@ def main():
                     ach = fl / (us * 1e-6) / 1e12
                     roofs[k] = {"bound": "mfma", "kernel": kern_name[k], "achieved": ach,
                                 "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS,
-                                "traffic": traffic.get(k) if (args.graphs, args.vars) == (31, 100) else None,
+                                "traffic": traffic.get(k) if default_cfg2 else None,
                                 "avg_launch_us": us,
                                 "launches_per_step": prof[k]["launches"] / steps_prof,
                                 "algorithmic_flops_per_launch": fl,
@@ -261,6 +396,7 @@ def main():
             # The sparse half-rounds run inside P2 / P3: their duration comes from in-kernel clock stamps
             # (a diagnostic session, DSAT_STAMPS=1), converted with the clock the same kernels ran at
             # (stamped tile cycles / event duration).  Bytes: SURVEY.md §8d unique-traffic model.
+            # tools/stamps.py writes the same stamps (and the per-phase table) under profiles/.
             try:
                 import ctypes as C
                 from diffusionsat_amd import _lib
@@ -273,11 +409,14 @@ def main():
                 buf = (C.c_int64 * (3 * 4096 * 8))()
                 _lib.check(_lib.load().dsat_session_read_stamps(s3.handle, buf, 3 * 4096 * 8))
                 st = np.frombuffer(buf, dtype=np.int64).reshape(3, 4096, 8)
-                t2 = st[1, :(c + 63) // 64].astype(np.float64)
-                t3 = st[2, :(n + 15) // 16].astype(np.float64)
+                t2 = st[1, :min((c + 63) // 64, 4096)].astype(np.float64)
+                t3 = st[2, :min((n + 15) // 16, 4096)].astype(np.float64)
                 g2, tot2 = np.median(t2[:, 2] - t2[:, 1]), np.median(t2[:, 4] - t2[:, 0])
                 g3, tot3 = np.median(t3[:, 1] - t3[:, 0]), np.median(t3[:, 3] - t3[:, 0])
                 rk = result["roofline_kernels"]
+                # a kernel lasts (tiles / 256 CUs, rounded up) tile times: the gather phase's share of it
+                w2 = -(-((c + 63) // 64) // 256)
+                w3 = -(-((n + 15) // 16) // 256)
                 us2 = g2 / tot2 * rk["round_p2_clause"]["avg_launch_us"]
                 us3 = g3 / tot3 * rk["round_p3_var_update"]["avg_launch_us"]
                 nbytes = sparse_bytes_per_round(n, c, e)
@@ -286,6 +425,8 @@ def main():
                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                     "algorithmic_bytes_per_round": nbytes, "gather_us_per_round": {"p2_literal_to_clause": us2,
                                                                                    "p3_clause_to_literal": us3},
+                    "gather_cycles_per_tile": {"p2": float(g2), "p3": float(g3)},
+                    "tile_waves": {"p2": w2, "p3": w3},
                     "note": "the four sparse products of a round (R3, R4, R7, R11) are the gather phases of the fused "
                             "P2 and P3 kernels; duration = that phase's share of the tile's stamped cycles x the "
                             "kernel's event duration; the rows are served by L2 / Infinity Cache (state written by the "
@@ -294,11 +435,11 @@ def main():
                 del s3
             except Exception as ex:      # diagnostics only: never fail the bench line
                 result["roofline_sparse"] = {"error": str(ex)}
-        if world == 1 and nflight == 1 and not args.no_profile and args.steps % 2 == 0:
+        if world == 1 and nflight == 1 and not args.no_profile and args.steps % 2 == 0 and args.config == 2:
             # secondary figure, same run: two independent config-2 batches in flight on two HIP streams
             # (what samples(n) can do when n needs more than one batch); never the headline `value`
-            b2 = make_batch(config2_instances(args.graphs, args.vars, seed=1002 + rank))
-            s2 = runtime.Session(runtime.Graph(b2), wts, max_rounds=args.rounds, device=dev)
+            b2 = make_batch(make_workload(args, 1002 + rank)[0])
+            s2 = runtime.Session(runtime.Graph(b2, device=dev), wts, max_rounds=args.rounds, device=dev)
             s2.set_graph_replay(not args.eager)
             extra.append((s2, torch.cuda.Stream(device=dev)))
             nflight = 2
@@ -313,7 +454,7 @@ def main():
             nflight = 1
             extra.clear()
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(instances, ws, args.rounds)
+            result["cpu_baseline"] = cpu_baseline(instances, ws, args.rounds, batch.n_nodes)
             result["cpu_baseline"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
     if dist is not None:
         dist.barrier()

@@ -46,6 +46,12 @@ SIGNATURES = {
     "dsat_graph_create": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _pp]),
     "dsat_graph_destroy": (None, [_vp]),
     "dsat_graph_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)]),
+    "dsat_arena_create": (C.c_int, [_i64, _i64, _pp]),
+    "dsat_arena_reset": (C.c_int, [_vp]),
+    "dsat_arena_usage": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "dsat_arena_destroy": (None, [_vp]),
+    "dsat_graph_create_in": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _pp]),
+    "dsat_session_create_in": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _pp]),
     "dsat_weights_load": (C.c_int, [_vp, _i64, C.POINTER(Layout), _pp]),
     "dsat_weights_destroy": (None, [_vp]),
     "dsat_session_create": (C.c_int, [_vp, _vp, _i32, _pp]),
@@ -56,6 +62,8 @@ SIGNATURES = {
     "dsat_diffusion_step_self": (C.c_int, [_vp, _f32, _vp, _vp, _vp, _vp, _u64, _u32, _i32, _i32,
                                             _vp, _vp, _vp, _vp, _vp, _vp]),
     "dsat_host_solve": (C.c_int, [_i32, _i32, _vp, _vp, C.c_int64, _vp, _vp]),
+    "dsat_host_gen_sr": (C.c_int, [_u64, _i32, _i32, C.c_double, C.c_double, C.c_double, C.POINTER(_i32),
+                                   C.POINTER(_i32), _vp, _i32, _vp, _i32]),
     "dsat_sample": (C.c_int, [_vp, _i32, _i32, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.POINTER(_f32), _vp]),
     "dsat_sample_self": (C.c_int, [_vp, _i32, _i32, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp,

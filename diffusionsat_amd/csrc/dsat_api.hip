@@ -48,12 +48,63 @@ static int require_device(int want, const char* who) {
     return DSAT_OK;
 }
 
+}  // namespace dsat
+
+// Device + pinned-host bump arena (include/dsat.h "pooled objects"): graphs and sessions created in
+// an arena cost no hipMalloc / hipFree (hipFree synchronises the whole device, which would drain the
+// other batches in flight) and upload through the arena's pinned staging area with asynchronous
+// copies on the caller's stream.
+struct dsat_arena {
+    int device = -1;
+    char* dev = nullptr;
+    size_t dev_cap = 0, dev_off = 0;
+    char* pin = nullptr;
+    size_t pin_cap = 0, pin_off = 0;
+    int live = 0;            // objects created in the arena and not yet destroyed
+    size_t dev_need = 0, pin_need = 0;   // high-water marks of requests (also of failed ones)
+    void* take_dev(size_t bytes) {
+        dev_off = (dev_off + 255) & ~size_t(255);
+        dev_need = std::max(dev_need, dev_off + bytes);
+        if (dev_off + bytes > dev_cap) { dev_off += bytes; return nullptr; }
+        void* p = dev + dev_off;
+        dev_off += bytes;
+        return p;
+    }
+    void* take_pin(size_t bytes) {
+        pin_off = (pin_off + 63) & ~size_t(63);
+        pin_need = std::max(pin_need, pin_off + bytes);
+        if (pin_off + bytes > pin_cap) { pin_off += bytes; return nullptr; }
+        void* p = pin + pin_off;
+        pin_off += bytes;
+        return p;
+    }
+};
+
+namespace dsat {
+
+// Upload `n` elements to a fresh device array: own allocation + synchronous copy, or (arena) a carve
+// of the arena + an asynchronous copy on `st` out of the arena's pinned staging area.
 template <typename T>
-static hipError_t up(T** dst, const T* src, size_t n) {
-    hipError_t e = hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T));
-    if (e != hipSuccess) return e;
-    if (n) e = hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice);
-    return e;
+static hipError_t up(dsat_arena* a, hipStream_t st, T** dst, const T* src, size_t n) {
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    if (a == nullptr) {
+        hipError_t e = hipMalloc((void**)dst, bytes);
+        if (e != hipSuccess) return e;
+        if (n) e = hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice);
+        return e;
+    }
+    *dst = static_cast<T*>(a->take_dev(bytes));
+    void* stage = n ? a->take_pin(n * sizeof(T)) : nullptr;
+    if (*dst == nullptr || (n && stage == nullptr)) return hipErrorOutOfMemory;
+    if (n == 0) return hipSuccess;
+    memcpy(stage, src, n * sizeof(T));
+    return hipMemcpyAsync(*dst, stage, n * sizeof(T), hipMemcpyHostToDevice, st);
+}
+static int arena_full(dsat_arena* a, const char* who) {
+    set_error(std::string(who) + ": arena too small (needs " + std::to_string(a->dev_need) + " device bytes and " +
+              std::to_string(a->pin_need) + " pinned bytes; has " + std::to_string(a->dev_cap) + " / " +
+              std::to_string(a->pin_cap) + ")");
+    return DSAT_E_INVALID;
 }
 
 // ---- bump allocator over one hipMalloc slab -------------------------------------
@@ -166,9 +217,9 @@ static int check_layout(const dsat_layout* L) {
 }
 
 // ============================================================================ graph
-extern "C" int dsat_graph_create(const int32_t* clause_rowptr, const int32_t* clause_lits,
-                                  const int32_t* var_graph_id, const int32_t* clause_graph_id,
-                                  int32_t N, int32_t C, int32_t G, dsat_graph** out) {
+static int graph_create_impl(dsat_arena* arena, hipStream_t st, const int32_t* clause_rowptr,
+                             const int32_t* clause_lits, const int32_t* var_graph_id,
+                             const int32_t* clause_graph_id, int32_t N, int32_t C, int32_t G, dsat_graph** out) {
     DSAT_REQUIRE(out != nullptr, DSAT_E_INVALID, "dsat_graph_create: null out");
     *out = nullptr;
     DSAT_REQUIRE(N > 0 && C >= 0 && G > 0, DSAT_E_INVALID, "dsat_graph_create: need n_vars>0, n_clauses>=0, n_graphs>0");
@@ -254,37 +305,108 @@ extern "C" int dsat_graph_create(const int32_t* clause_rowptr, const int32_t* cl
 
     std::unique_ptr<dsat_graph> g(new dsat_graph());
     { int rc = current_device(&g->device); if (rc != DSAT_OK) return rc; }
+    if (arena != nullptr) {
+        int rc = require_device(arena->device, "dsat_graph_create_in");
+        if (rc != DSAT_OK) return rc;
+        g->arena = arena;
+    }
     g->N = N; g->C = C; g->G = G; g->E = E;
     g->max_clause_len = max_len; g->max_lit_deg = max_deg;
     g->h_var_seg = vseg; g->h_cl_seg = cseg;
     g->h_c_rowptr.assign(clause_rowptr, clause_rowptr + C + 1);
     g->h_l_rowptr = l_rowptr;
     hipError_t e = hipSuccess;
-    if ((e = up(&g->c_rowptr, clause_rowptr, (size_t)C + 1)) != hipSuccess ||
-        (e = up(&g->c_lit, c_lit.data(), (size_t)E)) != hipSuccess ||
-        (e = up(&g->l_rowptr, l_rowptr.data(), 2 * (size_t)N + 1)) != hipSuccess ||
-        (e = up(&g->l_clause, l_clause.data(), (size_t)E)) != hipSuccess ||
-        (e = up(&g->var_gid, var_graph_id, (size_t)N)) != hipSuccess ||
-        (e = up(&g->cl_gid, clause_graph_id, (size_t)C)) != hipSuccess ||
-        (e = up(&g->var_seg, vseg.data(), (size_t)G + 1)) != hipSuccess ||
-        (e = up(&g->cl_seg, cseg.data(), (size_t)G + 1)) != hipSuccess ||
-        (e = up(&g->deg_w, deg_w.data(), 2 * (size_t)N)) != hipSuccess ||
-        (e = up(&g->vdeg_w, vdeg_w.data(), (size_t)N)) != hipSuccess ||
-        (e = up(&g->rev_w, rev_w.data(), (size_t)C)) != hipSuccess) {
-        dsat_graph_destroy(g.release());
+    if ((e = up(arena, st, &g->c_rowptr, clause_rowptr, (size_t)C + 1)) != hipSuccess ||
+        (e = up(arena, st, &g->c_lit, c_lit.data(), (size_t)E)) != hipSuccess ||
+        (e = up(arena, st, &g->l_rowptr, l_rowptr.data(), 2 * (size_t)N + 1)) != hipSuccess ||
+        (e = up(arena, st, &g->l_clause, l_clause.data(), (size_t)E)) != hipSuccess ||
+        (e = up(arena, st, &g->var_gid, var_graph_id, (size_t)N)) != hipSuccess ||
+        (e = up(arena, st, &g->cl_gid, clause_graph_id, (size_t)C)) != hipSuccess ||
+        (e = up(arena, st, &g->var_seg, vseg.data(), (size_t)G + 1)) != hipSuccess ||
+        (e = up(arena, st, &g->cl_seg, cseg.data(), (size_t)G + 1)) != hipSuccess ||
+        (e = up(arena, st, &g->deg_w, deg_w.data(), 2 * (size_t)N)) != hipSuccess ||
+        (e = up(arena, st, &g->vdeg_w, vdeg_w.data(), (size_t)N)) != hipSuccess ||
+        (e = up(arena, st, &g->rev_w, rev_w.data(), (size_t)C)) != hipSuccess) {
+        g->arena = nullptr;            // nothing counted yet
+        if (arena == nullptr) dsat_graph_destroy(g.release());
+        if (arena != nullptr && e == hipErrorOutOfMemory) return arena_full(arena, "dsat_graph_create_in");
         return hip_fail(e, "graph upload", __FILE__, __LINE__);
     }
+    if (arena != nullptr) arena->live++;
     *out = g.release();
     return DSAT_OK;
 }
 
+extern "C" int dsat_graph_create(const int32_t* clause_rowptr, const int32_t* clause_lits,
+                                  const int32_t* var_graph_id, const int32_t* clause_graph_id,
+                                  int32_t N, int32_t C, int32_t G, dsat_graph** out) {
+    return graph_create_impl(nullptr, nullptr, clause_rowptr, clause_lits, var_graph_id, clause_graph_id, N, C, G, out);
+}
+
+extern "C" int dsat_graph_create_in(dsat_arena* arena, void* stream, const int32_t* clause_rowptr,
+                                     const int32_t* clause_lits, const int32_t* var_graph_id,
+                                     const int32_t* clause_graph_id, int32_t N, int32_t C, int32_t G,
+                                     dsat_graph** out) {
+    DSAT_REQUIRE(arena != nullptr, DSAT_E_INVALID, "dsat_graph_create_in: null arena");
+    return graph_create_impl(arena, (hipStream_t)stream, clause_rowptr, clause_lits, var_graph_id, clause_graph_id,
+                             N, C, G, out);
+}
+
 extern "C" void dsat_graph_destroy(dsat_graph* g) {
     if (!g) return;
-    void* ptrs[] = {g->c_rowptr, g->c_lit, g->l_rowptr, g->l_clause, g->var_gid, g->cl_gid,
-                    g->var_seg, g->cl_seg, g->deg_w, g->vdeg_w, g->rev_w};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+    if (g->arena != nullptr) {
+        g->arena->live--;              // the arrays go back with dsat_arena_reset
+    } else {
+        void* ptrs[] = {g->c_rowptr, g->c_lit, g->l_rowptr, g->l_clause, g->var_gid, g->cl_gid,
+                        g->var_seg, g->cl_seg, g->deg_w, g->vdeg_w, g->rev_w};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
     delete g;
+}
+
+// ============================================================================ arena
+extern "C" int dsat_arena_create(int64_t device_bytes, int64_t pinned_bytes, dsat_arena** out) {
+    DSAT_REQUIRE(out != nullptr, DSAT_E_INVALID, "dsat_arena_create: null out");
+    *out = nullptr;
+    DSAT_REQUIRE(device_bytes > 0 && pinned_bytes > 0, DSAT_E_INVALID, "dsat_arena_create: sizes must be positive");
+    std::unique_ptr<dsat_arena> a(new dsat_arena());
+    { int rc = current_device(&a->device); if (rc != DSAT_OK) return rc; }
+    DSAT_HIP(hipMalloc((void**)&a->dev, (size_t)device_bytes));
+    hipError_t e = hipHostMalloc((void**)&a->pin, (size_t)pinned_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipFree(a->dev);
+        return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+    }
+    a->dev_cap = (size_t)device_bytes;
+    a->pin_cap = (size_t)pinned_bytes;
+    *out = a.release();
+    return DSAT_OK;
+}
+
+extern "C" int dsat_arena_reset(dsat_arena* a) {
+    DSAT_REQUIRE(a != nullptr, DSAT_E_INVALID, "dsat_arena_reset: null arena");
+    DSAT_REQUIRE(a->live == 0, DSAT_E_STATE,
+                 "dsat_arena_reset: " + std::to_string(a->live) + " object(s) created in the arena are still alive");
+    a->dev_off = a->pin_off = 0;
+    return DSAT_OK;
+}
+
+extern "C" int dsat_arena_usage(const dsat_arena* a, int64_t* device_used, int64_t* pinned_used,
+                                 int64_t* device_needed, int64_t* pinned_needed) {
+    DSAT_REQUIRE(a != nullptr, DSAT_E_INVALID, "dsat_arena_usage: null arena");
+    if (device_used) *device_used = (int64_t)a->dev_off;
+    if (pinned_used) *pinned_used = (int64_t)a->pin_off;
+    if (device_needed) *device_needed = (int64_t)a->dev_need;
+    if (pinned_needed) *pinned_needed = (int64_t)a->pin_need;
+    return DSAT_OK;
+}
+
+extern "C" void dsat_arena_destroy(dsat_arena* a) {
+    if (!a) return;
+    if (a->dev) (void)hipFree(a->dev);
+    if (a->pin) (void)hipHostFree(a->pin);
+    delete a;
 }
 
 extern "C" int dsat_graph_info(const dsat_graph* g, int32_t* n_vars, int32_t* n_clauses, int64_t* n_edges,
@@ -438,6 +560,7 @@ static const char* kKernelClassNames[KC_COUNT] = {
 
 struct dsat_session {
     int device = -1;
+    dsat_arena* arena = nullptr;   // non-null: the workspace slab is carved from this arena
     const dsat_graph* g = nullptr;
     const dsat_weights* w = nullptr;
     int max_rounds = 0;
@@ -695,8 +818,8 @@ static bool plan_round(dsat_session* s) {
     return ok;
 }
 
-extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, int32_t max_rounds,
-                                    dsat_session** out) {
+static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_graph* g, const dsat_weights* w,
+                               int32_t max_rounds, dsat_session** out) {
     DSAT_REQUIRE(out != nullptr, DSAT_E_INVALID, "dsat_session_create: null out");
     *out = nullptr;
     DSAT_REQUIRE(g && w, DSAT_E_INVALID, "dsat_session_create: null graph or weights");
@@ -727,8 +850,40 @@ extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, i
     Slab dry;
     carve(s.get(), dry);
     s->slab_bytes = dry.off + 256;
+    hipError_t e = hipSuccess;
+    if (arena != nullptr) {
+        int rc = require_device(arena->device, "dsat_session_create_in");
+        if (rc != DSAT_OK) return rc;
+        s->slab = static_cast<char*>(arena->take_dev(s->slab_bytes));
+        // staging for the four tile / segment tables
+        const size_t meta_bytes = (s->h_vmeta.size() + s->h_vgseg.size() + s->h_cmeta.size() + s->h_cgseg.size()) *
+                                  sizeof(int32_t) + 4 * 64;
+        char* stage = static_cast<char*>(arena->take_pin(meta_bytes));
+        if (s->slab == nullptr || stage == nullptr) return arena_full(arena, "dsat_session_create_in");
+        e = hipMemsetAsync(s->slab, 0, s->slab_bytes, st);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return hip_fail(e, "session init", __FILE__, __LINE__);
+        Slab real;
+        real.base = s->slab; real.size = s->slab_bytes; real.dry = false;
+        carve(s.get(), real);
+        auto cp = [&](int32_t* d, const std::vector<int32_t>& h) {
+            if (h.empty()) return hipSuccess;
+            memcpy(stage, h.data(), h.size() * sizeof(int32_t));
+            const hipError_t r = hipMemcpyAsync(d, stage, h.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+            stage += (h.size() * sizeof(int32_t) + 63) & ~size_t(63);
+            return r;
+        };
+        hipError_t e2 = cp(s->vmeta, s->h_vmeta);
+        if (e2 == hipSuccess) e2 = cp(s->vgseg, s->h_vgseg);
+        if (e2 == hipSuccess) e2 = cp(s->cmeta, s->h_cmeta);
+        if (e2 == hipSuccess) e2 = cp(s->cgseg, s->h_cgseg);
+        if (e2 != hipSuccess) {
+            (void)hipStreamDestroy(s->cap_stream);
+            return hip_fail(e2, "segment upload", __FILE__, __LINE__);
+        }
+    } else {
     DSAT_HIP(hipMalloc((void**)&s->slab, s->slab_bytes));
-    hipError_t e = hipMemset(s->slab, 0, s->slab_bytes);
+    e = hipMemset(s->slab, 0, s->slab_bytes);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         (void)hipFree(s->slab);
@@ -750,6 +905,7 @@ extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, i
             return hip_fail(e2, "segment upload", __FILE__, __LINE__);
         }
     }
+    }
     if (const char* ev = getenv("DSAT_STAMPS")) {
         if (atoi(ev) != 0) {
             DSAT_HIP(hipMalloc((void**)&s->stamps, 3 * 4096 * 8 * sizeof(long long)));
@@ -760,8 +916,20 @@ extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, i
     if (s->stamps) { s->ra1.stamps = s->stamps; s->ra2.stamps = s->stamps + 4096 * 8; s->ra3.stamps = s->stamps + 2 * 4096 * 8; }
     if (const char* ev = getenv("DSAT_FUSED")) s->use_fused = s->use_fused && atoi(ev) != 0;
     for (int i = 0; i < KC_COUNT; ++i) { s->prof_us[i] = 0; s->prof_n[i] = 0; }
+    if (arena != nullptr) { s->arena = arena; arena->live++; }
     *out = s.release();
     return DSAT_OK;
+}
+
+extern "C" int dsat_session_create(const dsat_graph* g, const dsat_weights* w, int32_t max_rounds,
+                                    dsat_session** out) {
+    return session_create_impl(nullptr, nullptr, g, w, max_rounds, out);
+}
+
+extern "C" int dsat_session_create_in(dsat_arena* arena, void* stream, const dsat_graph* g, const dsat_weights* w,
+                                       int32_t max_rounds, dsat_session** out) {
+    DSAT_REQUIRE(arena != nullptr, DSAT_E_INVALID, "dsat_session_create_in: null arena");
+    return session_create_impl(arena, (hipStream_t)stream, g, w, max_rounds, out);
 }
 
 extern "C" void dsat_session_destroy(dsat_session* s) {
@@ -769,7 +937,8 @@ extern "C" void dsat_session_destroy(dsat_session* s) {
     for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->cap_stream) (void)hipStreamDestroy(s->cap_stream);
-    if (s->slab) (void)hipFree(s->slab);
+    if (s->arena != nullptr) s->arena->live--;
+    else if (s->slab) (void)hipFree(s->slab);
     if (s->stamps) (void)hipFree(s->stamps);
     delete s;
 }

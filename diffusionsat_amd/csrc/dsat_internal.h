@@ -63,8 +63,11 @@ struct dsat_weights {
     size_t slab_bytes = 0;
 };
 
+struct dsat_arena;
+
 struct dsat_graph {
     int device = -1;   // HIP device the arrays live on (the current device at dsat_graph_create)
+    dsat_arena* arena = nullptr;   // non-null: the device arrays are carved from this arena (not freed one by one)
     int32_t N = 0, C = 0, G = 0;
     int64_t E = 0;
     int32_t max_clause_len = 0, max_lit_deg = 0;

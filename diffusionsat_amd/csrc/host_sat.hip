@@ -10,7 +10,9 @@
 // Only SAT/UNSAT (and one model) matter to the generators, so nothing here has to match
 // Glucose's search order.
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "dsat_internal.h"
@@ -163,7 +165,7 @@ struct Cdcl {
     int solve(int64_t conflict_limit) {
         if (!ok) return 0;
         if (propagate() >= 0) { ok = false; return 0; }
-        int64_t restart_at = 100;
+        int64_t restart_at = conflicts + 100;   // `conflicts` accumulates over incremental calls
         std::vector<int> learnt;
         for (;;) {
             const int confl = propagate();
@@ -222,5 +224,137 @@ extern "C" int dsat_host_solve(int32_t n_vars, int32_t n_clauses, const int32_t*
     *result_out = r;
     if (r == 1 && model_out != nullptr)
         for (int v = 0; v < n_vars; ++v) model_out[v] = s.val[v] == 1 ? 1 : 0;
+    return DSAT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NeuroSAT-style SR(n) instance generator (data/k_sat.py:36-93), natively: the reference adds
+// random clauses of width k = (1 w.p. p_k_2 else 2) + Geometric(p_geo) to an incremental PySAT
+// solver until it reports UNSAT, negates the first literal of the last clause (which makes the
+// formula satisfiable again), removes duplicate and subsumed clauses (utils/DimacsFile.py:110-128)
+// and, for a desired multiplier of the number of solutions > 1, drops round(log_x(multiplier))
+// random clauses with x = 2^(n/m) (:66-84).  A 100 000-instance stream (BASELINE config 4) needs
+// this at native speed; the random stream is this file's own (splitmix64), not Python's.
+namespace {
+
+struct SplitMix {
+    uint64_t s;
+    explicit SplitMix(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }   // [0,1)
+    int below(int n) { return (int)(uniform() * n); }
+    int geometric(double p) {   // trials up to and including the first success, support {1,2,...}
+        const double u = uniform();
+        const double k = std::ceil(std::log1p(-u) / std::log1p(-p));
+        return k < 1.0 ? 1 : (k > 1e6 ? 1000000 : (int)k);
+    }
+};
+
+// Dedup + subsumption with the order of diffusionsat_amd/dimacs.py::reduce_clauses: literals of a
+// clause ascending (signed), clauses by (length, lexicographic); a clause that contains an earlier
+// kept clause is dropped.
+void reduce_clauses(std::vector<std::vector<int>>& cls) {
+    for (auto& c : cls) {
+        std::sort(c.begin(), c.end());
+        c.erase(std::unique(c.begin(), c.end()), c.end());   // reduce_clauses goes through set(tuple(sorted))
+    }
+    std::sort(cls.begin(), cls.end(), [](const std::vector<int>& a, const std::vector<int>& b) {
+        if (a.size() != b.size()) return a.size() < b.size();
+        return a < b;
+    });
+    cls.erase(std::unique(cls.begin(), cls.end()), cls.end());
+    std::vector<std::vector<int>> kept;
+    for (const auto& c : cls) {
+        bool sub = false;
+        for (const auto& k : kept) {
+            if (k.size() > c.size()) break;   // kept is ordered by length
+            if (std::includes(c.begin(), c.end(), k.begin(), k.end())) { sub = true; break; }
+        }
+        if (!sub) kept.push_back(c);
+    }
+    cls.swap(kept);
+}
+
+}  // namespace
+
+extern "C" int dsat_host_gen_sr(uint64_t seed, int32_t min_vars, int32_t max_vars, double p_k_2, double p_geo,
+                                double solutions_multiplier, int32_t* n_vars_out, int32_t* n_clauses_out,
+                                int32_t* clause_rowptr_out, int32_t rowptr_cap, int32_t* clause_lits_out,
+                                int32_t lits_cap) {
+    using namespace dsat;
+    DSAT_REQUIRE(n_vars_out && n_clauses_out && clause_rowptr_out && clause_lits_out, DSAT_E_INVALID,
+                 "dsat_host_gen_sr: null output");
+    DSAT_REQUIRE(min_vars >= 1 && max_vars >= min_vars && max_vars <= 100000, DSAT_E_INVALID,
+                 "dsat_host_gen_sr: need 1 <= min_vars <= max_vars");
+    DSAT_REQUIRE(p_k_2 >= 0.0 && p_k_2 <= 1.0 && p_geo > 0.0 && p_geo <= 1.0, DSAT_E_INVALID,
+                 "dsat_host_gen_sr: probabilities out of range");
+    SplitMix rng(seed * 0x2545F4914F6CDD1Dull + 0x1234567ull);
+    const int n = min_vars + rng.below(max_vars - min_vars + 1);       // random.randint(min, max)
+    Cdcl solver(n);
+    std::vector<std::vector<int>> clauses;   // signed DIMACS literals
+    std::vector<int> perm(n);
+    std::vector<int> last;
+    for (;;) {
+        const int k_base = rng.uniform() < p_k_2 ? 1 : 2;
+        const int k = std::min(n, k_base + (p_geo >= 1.0 ? 1 : rng.geometric(p_geo)));
+        for (int i = 0; i < n; ++i) perm[i] = i;
+        std::vector<int> c(k), enc(k);
+        for (int i = 0; i < k; ++i) {   // np.random.choice(n, k, replace=False): partial Fisher-Yates
+            const int j = i + rng.below(n - i);
+            std::swap(perm[i], perm[j]);
+            const int v = perm[i];
+            const bool pos = rng.uniform() < 0.5;
+            c[i] = pos ? v + 1 : -(v + 1);
+            enc[i] = pos ? 2 * v : 2 * v + 1;
+        }
+        solver.backtrack(0);
+        const bool alive = solver.add(enc);
+        const int r = alive ? solver.solve(0) : 0;
+        if (r == 1) {
+            clauses.push_back(c);
+        } else {
+            last = c;
+            break;
+        }
+    }
+    last[0] = -last[0];          // the SAT member of NeuroSAT's SR(n) pair (k_sat.py:57-64)
+    clauses.push_back(last);
+    reduce_clauses(clauses);
+    if (solutions_multiplier > 1.0 && !clauses.empty()) {
+        const int m = (int)clauses.size();
+        const double x = std::pow(2.0, (double)n / m);
+        double d = std::nearbyint(std::log(solutions_multiplier) / std::log(x));   // Python round(): half to even
+        d = std::max(0.0, std::min(d, (double)(m - 1)));
+        std::vector<int> idx(m);
+        for (int i = 0; i < m; ++i) idx[i] = i;
+        std::vector<char> drop(m, 0);
+        for (int i = 0; i < (int)d; ++i) {   // random.sample(range(m), d)
+            const int j = i + rng.below(m - i);
+            std::swap(idx[i], idx[j]);
+            drop[idx[i]] = 1;
+        }
+        std::vector<std::vector<int>> kept;
+        for (int i = 0; i < m; ++i)
+            if (!drop[i]) kept.push_back(clauses[i]);
+        clauses.swap(kept);
+    }
+    int64_t total = 0;
+    for (const auto& c : clauses) total += (int64_t)c.size();
+    *n_vars_out = n;
+    *n_clauses_out = (int32_t)clauses.size();
+    DSAT_REQUIRE((int64_t)clauses.size() + 1 <= rowptr_cap && total <= lits_cap, DSAT_E_INVALID,
+                 "dsat_host_gen_sr: output buffers too small (need " + std::to_string(clauses.size() + 1) +
+                     " row pointers and " + std::to_string(total) + " literals)");
+    clause_rowptr_out[0] = 0;
+    int32_t e = 0;
+    for (size_t ci = 0; ci < clauses.size(); ++ci) {
+        for (int l : clauses[ci]) clause_lits_out[e++] = l;
+        clause_rowptr_out[ci + 1] = e;
+    }
     return DSAT_OK;
 }

@@ -14,7 +14,7 @@ from typing import Dict, List, Sequence
 import torch
 import torch.distributed as dist
 
-from .batch import Instance, sat_node_count
+from .batch import Instance, instance_size, sat_node_count
 
 
 def broadcast_weight_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
@@ -28,13 +28,12 @@ def broadcast_weight_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
 def shard_instances(instances: Sequence[Instance], rank: int, world_size: int) -> List[Instance]:
     """Whole formulas to ranks, largest first onto the least-loaded rank (node count
     ``2n+m``, data/dimac.py:172-174), deterministic on every rank."""
-    order = sorted(range(len(instances)),
-                   key=lambda i: (-sat_node_count(int(instances[i][0]), len(instances[i][1])), i))
+    order = sorted(range(len(instances)), key=lambda i: (-sat_node_count(*instance_size(instances[i])), i))
     load = [0] * world_size
     mine: List[int] = []
     for i in order:
         r = min(range(world_size), key=lambda k: (load[k], k))
-        load[r] += sat_node_count(int(instances[i][0]), len(instances[i][1]))
+        load[r] += sat_node_count(*instance_size(instances[i]))
         if r == rank:
             mine.append(i)
     return [instances[i] for i in sorted(mine)]

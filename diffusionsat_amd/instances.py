@@ -187,3 +187,41 @@ def sr_ksat(seed: int = 0, min_vars: int = 30, max_vars: int = 100, p_k_2: float
         drop = set(int(i) for i in rng.choice(m, size=d, replace=False))
         clauses = [c for i, c in enumerate(clauses) if i not in drop]
     return n, clauses
+
+
+def sr_ksat_native(seed: int = 0, min_vars: int = 30, max_vars: int = 100, p_k_2: float = 0.3, p_geo: float = 0.4,
+                   solutions_multiplier: float = 10.0):
+    """``sr_ksat`` generated by the extension itself (``dsat_host_gen_sr``: incremental CDCL instead of one
+    solver call per clause from Python; its own random stream, so not draw-for-draw ``sr_ksat``).
+    ``solutions_multiplier`` defaults to the reference's 10 (data/k_sat.py:21).  Returns a
+    ``CompactInstance`` (flat arrays)."""
+    import ctypes as C
+    from . import _lib
+    from .batch import CompactInstance
+    lib = _lib.load()
+    cap_c, cap_l = 64 * max_vars + 64, 64 * max_vars * 8
+    while True:
+        rowptr = np.zeros(cap_c, dtype=np.int32)
+        lits = np.zeros(cap_l, dtype=np.int32)
+        n, m = C.c_int32(0), C.c_int32(0)
+        rc = lib.dsat_host_gen_sr(int(seed), int(min_vars), int(max_vars), float(p_k_2), float(p_geo),
+                                  float(solutions_multiplier), C.byref(n), C.byref(m),
+                                  rowptr.ctypes.data_as(C.c_void_p), cap_c, lits.ctypes.data_as(C.c_void_p), cap_l)
+        if rc == 0:
+            break
+        if b"too small" not in lib.dsat_last_error():
+            _lib.check(rc)
+        cap_c, cap_l = cap_c * 4, cap_l * 4
+    m = m.value
+    return CompactInstance(n.value, rowptr[:m + 1].copy(), lits[:rowptr[m]].copy())
+
+
+def sr_stream(count: int, seed: int = 4, threads: int = 0, **kw):
+    """``count`` SR(n) instances of the config-4 stream (seeds seed*2^32 + i), generated on a thread pool
+    (the ctypes call releases the GIL)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or min(16, os.cpu_count() or 1)
+    base = int(seed) << 32
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(lambda i: sr_ksat_native(base + i, **kw), range(int(count))))

@@ -54,20 +54,63 @@ def _on_device(fn):
     return wrapper
 
 
-class Graph:
-    """Device-resident CSR clause-literal graph of one batch (``dsat_graph``)."""
+class Arena:
+    """Device + pinned-host bump arena (``dsat_arena``): graphs and sessions created in it cost no
+    hipMalloc / hipFree and upload asynchronously on the current stream (include/dsat.h, "pooled
+    objects").  ``reset()`` gives everything back once the objects created in it are closed."""
 
-    def __init__(self, batch: Batch, device=None):
+    def __init__(self, device_bytes: int, pinned_bytes: int, device=None):
+        lib = _lib.load()
+        self.device = _device(device)
+        self.device_bytes, self.pinned_bytes = int(device_bytes), int(pinned_bytes)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.dsat_arena_create(self.device_bytes, self.pinned_bytes, C.byref(h)))
+        self.handle = h
+
+    def reset(self):
+        _lib.check(_lib.load().dsat_arena_reset(self.handle))
+
+    def usage(self):
+        v = [C.c_int64(0) for _ in range(4)]
+        _lib.check(_lib.load().dsat_arena_usage(self.handle, *[C.byref(x) for x in v]))
+        return {"device_used": v[0].value, "pinned_used": v[1].value, "device_needed": v[2].value,
+                "pinned_needed": v[3].value}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            with torch.cuda.device(self.device):
+                _lib.load().dsat_arena_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Graph:
+    """Device-resident CSR clause-literal graph of one batch (``dsat_graph``).  With ``arena`` the
+    device arrays come from that arena and the upload is asynchronous on the current stream."""
+
+    def __init__(self, batch: Batch, device=None, arena: Optional[Arena] = None):
         lib = _lib.load()
         self.batch = batch
-        self.device = _device(device)
+        self.arena = arena
+        self.device = arena.device if (arena is not None and device is None) else _device(device)
         self._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in
                       (batch.clause_rowptr, batch.clause_lits, batch.var_graph_id, batch.clause_graph_id)]
         h = C.c_void_p()
         args = [a.ctypes.data_as(C.c_void_p) if a.size else None for a in self._keep]
         with torch.cuda.device(self.device):
-            _lib.check(lib.dsat_graph_create(args[0], args[1], args[2], args[3], batch.n_vars, batch.n_clauses,
-                                             batch.n_graphs, C.byref(h)))
+            if arena is None:
+                _lib.check(lib.dsat_graph_create(args[0], args[1], args[2], args[3], batch.n_vars, batch.n_clauses,
+                                                 batch.n_graphs, C.byref(h)))
+            else:
+                _lib.check(lib.dsat_graph_create_in(arena.handle, _stream(self.device), args[0], args[1], args[2],
+                                                    args[3], batch.n_vars, batch.n_clauses, batch.n_graphs,
+                                                    C.byref(h)))
         self.handle = h
         self.n_vars, self.n_clauses, self.n_graphs, self.n_edges = (
             batch.n_vars, batch.n_clauses, batch.n_graphs, batch.n_edges)
@@ -126,9 +169,11 @@ class Weights:
 class Session:
     """Workspace + launch sequence for one (graph, weights) pair (``dsat_session``)."""
 
-    def __init__(self, graph: Graph, weights: Weights, max_rounds: int = 32, device=None):
+    def __init__(self, graph: Graph, weights: Weights, max_rounds: int = 32, device=None,
+                 arena: Optional[Arena] = None):
         lib = _lib.load()
         self.graph, self.weights = graph, weights
+        self.arena = arena
         self.device = graph.device if device is None else _device(device)
         if not (self.device == graph.device == weights.device):
             raise ValueError("session on %s, graph on %s, weights on %s: all three must share one GPU"
@@ -136,7 +181,11 @@ class Session:
         self.max_rounds = max_rounds
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(lib.dsat_session_create(graph.handle, weights.handle, max_rounds, C.byref(h)))
+            if arena is None:
+                _lib.check(lib.dsat_session_create(graph.handle, weights.handle, max_rounds, C.byref(h)))
+            else:
+                _lib.check(lib.dsat_session_create_in(arena.handle, _stream(self.device), graph.handle,
+                                                      weights.handle, max_rounds, C.byref(h)))
         self.handle = h
 
     # -- the hot path ----------------------------------------------------------------

@@ -111,6 +111,29 @@ void dsat_session_destroy(dsat_session* s);
 /* 1 (default) = replay each denoising step from a captured hipGraph; 0 = eager. */
 int dsat_session_set_graph_replay(dsat_session* s, int32_t enable);
 
+/* ---- pooled objects (streams of batches) ----------------------------------------------------------
+ * A stream of node-budget batches (data/dimac.py:267-293 feeding QuerySAT batch after batch) creates a
+ * graph and a session per batch.  An arena is one device allocation plus one pinned host staging
+ * area, made once: graphs and sessions created "in" it take their device memory from it (no
+ * hipMalloc / hipFree per batch -- hipFree synchronises the whole device and would drain the other
+ * batches in flight) and upload through the staging area with asynchronous copies on `stream`.
+ * Use the same stream for the calls that follow (or synchronise): the uploads are stream-ordered.
+ * dsat_arena_reset gives all of it back at once; every object created in the arena must have been
+ * destroyed and its work finished.  A request that does not fit returns DSAT_E_INVALID; the sizes
+ * it would have needed are reported by dsat_arena_usage (device_needed / pinned_needed). */
+typedef struct dsat_arena dsat_arena;
+int dsat_arena_create(int64_t device_bytes, int64_t pinned_bytes, dsat_arena** out);
+int dsat_arena_reset(dsat_arena* a);
+int dsat_arena_usage(const dsat_arena* a, int64_t* device_used, int64_t* pinned_used,
+                     int64_t* device_needed, int64_t* pinned_needed);
+void dsat_arena_destroy(dsat_arena* a);
+int dsat_graph_create_in(dsat_arena* arena, void* stream, const int32_t* clause_rowptr,
+                         const int32_t* clause_lits, const int32_t* var_graph_id,
+                         const int32_t* clause_graph_id, int32_t n_vars, int32_t n_clauses,
+                         int32_t n_graphs, dsat_graph** out);
+int dsat_session_create_in(dsat_arena* arena, void* stream, const dsat_graph* g, const dsat_weights* w,
+                           int32_t max_rounds, dsat_session** out);
+
 /* One denoising step = QuerySAT.diffusion_step (model/query_sat.py:467-481) ->
  * call (:133-184) -> loop (:186-373) at inference, for `rounds` message-passing
  * rounds.
@@ -258,6 +281,19 @@ int dsat_session_set_tap(dsat_session* s, const dsat_tap* tap);
 int dsat_host_solve(int32_t n_vars, int32_t n_clauses, const int32_t* clause_rowptr,
                     const int32_t* clause_lits, int64_t conflict_limit, int32_t* result_out,
                     uint8_t* model_out);
+
+/* One draw of the reference's NeuroSAT-style SR(n) generator (data/k_sat.py:36-93), natively: clauses
+ * of width k = (1 w.p. p_k_2 else 2) + Geometric(p_geo) over distinct variables are added while the
+ * formula stays satisfiable; the clause that makes it unsatisfiable gets its first literal negated;
+ * duplicate and subsumed clauses are removed (utils/DimacsFile.py:110-128); for
+ * solutions_multiplier > 1 some clauses are dropped (:66-84; the reference's default is 10).
+ * n = uniform in [min_vars, max_vars].  Deterministic in `seed` (this library's own random stream,
+ * not Python's).  Outputs: *n_vars_out, *n_clauses_out, clause CSR with signed DIMACS literals
+ * (rowptr needs n_clauses+1 entries); DSAT_E_INVALID when a buffer is too small. */
+int dsat_host_gen_sr(uint64_t seed, int32_t min_vars, int32_t max_vars, double p_k_2, double p_geo,
+                     double solutions_multiplier, int32_t* n_vars_out, int32_t* n_clauses_out,
+                     int32_t* clause_rowptr_out, int32_t rowptr_cap, int32_t* clause_lits_out,
+                     int32_t lits_cap);
 
 #ifdef __cplusplus
 }

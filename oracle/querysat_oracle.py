@@ -283,6 +283,11 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
                           "best_map", "per_graph_loss", "variables_grad", "is_sat",
                           "literals", "clauses_loss4", "clause_messages", "variables_loss_all",
                           "new_clause_value", "variables_loss", "new_variables")}
+    keep = set(tr) if trace is True else (set(trace) if trace else set())   # trace=("logits", ...) keeps a subset
+
+    def rec(key, value):
+        if key in keep:
+            tr[key].append(np.array(value, copy=True))
     for step in range(rounds):                                       # :225
         v1 = np.concatenate([variables, np.asarray(normal[step], dtype=dt), noisy_labels], axis=-1)  # :239
         query = mlp(v1, w["variables_query"])                        # :240
@@ -302,10 +307,10 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
         variables_loss_all = clause_data[:, :QUERY_MAPS]            # :263
         new_clause_value = clause_data[:, QUERY_MAPS:]              # :264
         if trace:   # pre-normalisation values (the tensors the fused kernels' debug taps expose)
-            tr["literals"].append(literals.copy()); tr["clauses_loss4"].append(clauses_loss.copy())
-            tr["clause_messages"].append(clause_messages.copy())
-            tr["variables_loss_all"].append(variables_loss_all.copy())
-            tr["new_clause_value"].append(new_clause_value.copy())
+            rec("literals", literals); rec("clauses_loss4", clauses_loss)
+            rec("clause_messages", clause_messages)
+            rec("variables_loss_all", variables_loss_all)
+            rec("new_clause_value", new_clause_value)
         new_clause_value = pair_norm(new_clause_value, cg_norm, cmask) * f(0.25)  # :265
         clause_state = new_clause_value + f(0.1) * clause_state     # :266
 
@@ -315,7 +320,7 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
         unit = np.concatenate([variables_grad, v1, vl_pos, vl_neg], axis=-1)  # :277
         new_variables = mlp(unit, w["update_gate"])                 # :278
         if trace:
-            tr["variables_loss"].append(variables_loss.copy()); tr["new_variables"].append(new_variables.copy())
+            rec("variables_loss", variables_loss); rec("new_variables", new_variables)
         new_variables = pair_norm(new_variables, vg_norm, vmask) * f(0.25)  # :279
         variables = new_variables + f(0.1) * variables              # :280
 
@@ -328,11 +333,12 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
         is_sat = is_batch_sat(out_logits, cl_adj)                   # :330
         last_logits = logits                                         # :337 / :339
         if trace:
-            tr["logits"].append(logits.copy()); tr["query"].append(query.copy())
-            tr["clause_state"].append(clause_state.copy()); tr["variables"].append(variables.copy())
-            tr["out_logits"].append(out_logits[:, 0].copy()); tr["best_map"].append(best_map.copy())
-            tr["per_graph_loss"].append(per_graph_loss.copy()); tr["variables_grad"].append(variables_grad.copy())
-            tr["is_sat"].append(float(is_sat))
+            rec("logits", logits); rec("query", query)
+            rec("clause_state", clause_state); rec("variables", variables)
+            rec("out_logits", out_logits[:, 0]); rec("best_map", best_map)
+            rec("per_graph_loss", per_graph_loss); rec("variables_grad", variables_grad)
+            if "is_sat" in keep:
+                tr["is_sat"].append(float(is_sat))
         if early_exit and is_sat == 1:                               # :331-338
             break
         # :347-348  x*0.2 + x*0.8 (forward value only)

@@ -60,6 +60,87 @@ def test_world_size_two_gloo():
     assert res[0][4] + res[1][4] == 7
 
 
+class _FakeDeviceSampler:
+    """Mixin that replaces the two device hooks of DiffusionSampler (``_launch`` / ``_collect``) by a
+    host stand-in: random bits from the batch's seed, per-copy SAT flags from the formula.  Everything
+    else -- budget split, Philox sub-stream seeds, decoding, abort rule, merge -- is the product code."""
+
+    def _launch(self, it, copies, seed):
+        return copies, seed
+
+    def _collect(self, handle):
+        from diffusionsat_amd.dimacs import VariableAssignment
+        copies, seed = handle
+        bits = np.random.default_rng(seed).integers(0, 2, copies * self.n_vars).astype(np.uint8)
+        va = VariableAssignment(n_vars=self.n_vars, clauses=self.clauses)
+        solved = np.zeros(copies, bool)
+        for i in range(copies):
+            va.assign_all_from_bit_list(bits[i * self.n_vars:(i + 1) * self.n_vars])
+            solved[i] = va.satisfiable()
+        return bits, solved
+
+
+def _make_fake_sampler(path, rank, world):
+    from diffusionsat_amd.diffusion_sampler import DiffusionSampler
+
+    class S(_FakeDeviceSampler, DiffusionSampler):
+        pass
+    return S(None, path, device="cuda:0", seed=5, rank=rank, world_size=world, copies_per_batch=7)
+
+
+def _sampler_worker(rank, world, port, path, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        smp = _make_fake_sampler(path, rank, world)
+        res = smp.samples(23)
+        q.put((rank, {str(k): v for k, v in res.items()}, smp.success_rate))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_diffusion_sampler_samples_world_size_two(tmp_path):
+    """DiffusionSampler.samples with world_size 2 over gloo: every rank draws its share of the budget
+    from its own seeds and both return the same merged dictionary = the union of what each rank's
+    local loop produces (recomputed here in one process with the same stand-in device hooks)."""
+    from diffusionsat_amd.dimacs import DimacsFile
+    cnf = tmp_path / "f.cnf"
+    DimacsFile(str(cnf), clauses=[[1, 2], [-2, 3], [3, 4, -5], [-1, -4]]).store()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sampler_worker, args=(r, world, port, str(cnf), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]          # both ranks hold the merged result
+    want, tot, sat = {}, 0, 0
+    for r in range(world):
+        local, t, s = _make_fake_sampler(str(cnf), r, world)._samples_local(D.split_sample_budget(23, r, world))
+        assert sum(local.values()) == D.split_sample_budget(23, r, world)
+        tot, sat = tot + t, sat + s
+        for k, v in local.items():
+            want[str(k)] = want.get(str(k), 0) + v
+    assert res[0][1] == want and sum(want.values()) == 23
+    assert abs(res[0][2] - sat / tot) < 1e-12
+    # world_size > 1 without an initialised process group is an error, not a silent single-rank run
+    with pytest.raises(RuntimeError):
+        _make_fake_sampler(str(cnf), 0, 2).samples(3)
+
+
+def test_epoch_batch_sizes_follow_the_reference_batcher():
+    from diffusionsat_amd.diffusion_sampler import epoch_batch_sizes
+    assert epoch_batch_sizes(10, 4) == [4, 4]                 # copies 5 and 10 overflow a batch and are lost (F11)
+    assert epoch_batch_sizes(10, 4, reference_drop_bug=False) == [4, 4, 2]
+    assert epoch_batch_sizes(3, 4) == [3] and epoch_batch_sizes(0, 4) == []
+    assert epoch_batch_sizes(3, 1) == [1, 1]                  # a formula larger than the budget: alone in its batch
+
+
 def test_single_process_helpers():
     assert D.merge_counts({3: 1}) == {3: 1}
     assert [D.split_sample_budget(10, r, 4) for r in range(4)] == [3, 3, 2, 2]

@@ -1,0 +1,204 @@
+"""GPU tests of the BASELINE.json configurations the round-1 suite did not reach at their size:
+config 3 at T=64 x R=32, config 4 (mixed-width SR(n) k-SAT: a 20k-node batch against the oracle, and
+the pooled streaming pipeline), config 5 (irregular-degree CNF at ~10k variables, and a <= 3k-variable
+instance against the oracle for the full 32 rounds).  Configs 1 and 2 are in test_gpu_parity.py /
+test_gpu_fullsize.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import draws, oracle_weights
+from oracle import querysat_oracle as O
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    from diffusionsat_amd import runtime
+    return runtime
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _host_check(batch, assignment, solved):
+    """Every graph flagged solved really is satisfied by its bits (independent NumPy check)."""
+    lits = batch.clause_lits.astype(np.int64)
+    val = np.where(lits > 0, assignment[np.abs(lits) - 1] == 1, assignment[np.abs(lits) - 1] == 0)
+    clause_sat = np.add.reduceat(val.astype(np.int64), batch.clause_rowptr[:-1].astype(np.int64)) > 0
+    unsat_per_graph = np.bincount(batch.clause_graph_id, weights=(~clause_sat).astype(np.float64),
+                                  minlength=batch.n_graphs)
+    really = unsat_per_graph == 0
+    assert np.all(really[solved]), "a graph flagged solved has an unsatisfied clause"
+    return really
+
+
+# ------------------------------------------------------------------------------------------ config 3
+def test_config3_full_length_sampler(rt):
+    """BASELINE config 3 as specified: 256 copies of one n=100 threshold instance (160 768 nodes),
+    T=64 denoising steps x R=32 rounds, device RNG.  Determinism run to run, {0,1} outputs, every
+    solved flag re-checked on the host, copies with different noise end in different assignments."""
+    from diffusionsat_amd.batch import make_batch
+    from diffusionsat_amd.instances import config3_instances
+    batch = make_batch(config3_instances(256, 100, seed=2))
+    assert batch.n_nodes == 160768 and batch.n_graphs == 256
+    s = rt.Session(rt.Graph(batch), rt.Weights(oracle_weights(1)), max_rounds=32)
+    out = s.sample(64, 32, seed=11, early_exit=True)
+    asg = out["assignment"].cpu().numpy()
+    solved = out["solved"].cpu().numpy() > 0
+    assert set(np.unique(asg)) <= {0, 1} and asg.shape == (256 * 100,)
+    _host_check(batch, asg, solved)
+    assert abs(out["solved_fraction"] - solved.mean()) < 1e-6
+    again = s.sample(64, 32, seed=11, early_exit=True)
+    assert torch.equal(again["assignment"], out["assignment"]) and torch.equal(again["solved"], out["solved"])
+    assert len({asg[g * 100:(g + 1) * 100].tobytes() for g in range(256)}) > 200       # per-copy noise differs
+    other = s.sample(64, 32, seed=12, early_exit=True)
+    assert not torch.equal(other["assignment"], out["assignment"])
+
+
+# ------------------------------------------------------------------------------------------ config 4
+def _sr_batch(n_nodes_budget=20000, seed0=100):
+    from diffusionsat_amd.batch import make_batch, sat_node_count
+    from diffusionsat_amd.instances import sr_ksat_native
+    insts, nodes, i = [], 0, 0
+    while True:
+        x = sr_ksat_native((4 << 32) + seed0 + i)
+        cnt = sat_node_count(x.n_vars, x.n_clauses)
+        if nodes + cnt > n_nodes_budget:
+            break
+        insts.append(x)
+        nodes += cnt
+        i += 1
+    return insts, make_batch(insts)
+
+
+def test_config4_mixed_k_batch_matches_oracle_and_single_graphs(rt):
+    """A ~20k-node batch of NeuroSAT-style SR(n) instances (clause widths 2..n mixed, n in [30,100], graphs of
+    different sizes straddling tiles): 4 rounds of per-round logits against the oracle, and the
+    block-diagonal property -- three of its graphs run alone give the batch's rows."""
+    from diffusionsat_amd.batch import make_batch
+    insts, batch = _sr_batch()
+    assert 19000 < batch.n_nodes <= 20000 and batch.n_graphs > 25
+    widths = np.diff(batch.clause_rowptr)
+    assert widths.min() <= 2 and widths.max() >= 8                     # really mixed-width
+    plain = [i.as_instance() for i in insts]
+    data = O.create_adj_matrices(plain)
+    ws = oracle_weights(12)
+    rounds = 4
+    d = draws(batch.n_vars, rounds, seed=31)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.6), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32, trace=("logits",))
+    w = rt.Weights(ws)
+    s = rt.Session(rt.Graph(batch), w, max_rounds=rounds)
+    out = s.diffusion_step(0.6, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds, early_exit=False,
+                           want_logits=True, want_round_logits=True)
+    got = out["round_logits"].cpu().numpy()
+    for r in range(rounds):
+        assert np.abs(got[r] - ref["trace"]["logits"][r]).max() < 2e-4, r
+    off = np.concatenate([[0], np.cumsum(batch.variables_in_graph)])
+    for g in (0, batch.n_graphs // 2, batch.n_graphs - 1):
+        sl = slice(int(off[g]), int(off[g + 1]))
+        s1 = rt.Session(rt.Graph(make_batch([insts[g]])), w, max_rounds=rounds)
+        o1 = s1.diffusion_step(0.6, _dev(noisy[sl]), _dev(d["normal"][:, sl]), _dev(d["labels"][sl]), rounds=rounds,
+                               early_exit=False, want_logits=True)
+        assert np.abs(o1["logits"].cpu().numpy() - got[-1][sl]).max() < 2e-5, g
+
+
+def test_config4_stream_pipeline_equals_batch_by_batch(rt):
+    """The streaming pipeline (pooled arenas, two batches in flight, results in stream order) returns,
+    batch for batch, exactly what a plain session per batch returns; so does the unpooled variant; an
+    arena that starts too small grows instead of failing."""
+    from diffusionsat_amd.batch import batch_by_node_budget, make_batch
+    from diffusionsat_amd.instances import sr_ksat_native
+    from diffusionsat_amd.stream import StreamSampler
+    insts = [sr_ksat_native((4 << 32) + 7000 + i, min_vars=10, max_vars=40) for i in range(60)]
+    batches = [make_batch(g) for g in batch_by_node_budget(insts, 2500)]
+    assert len(batches) >= 5 and len({b.n_nodes for b in batches}) > 1
+    w = rt.Weights(oracle_weights(2))
+    T, R, seed = 3, 6, 41
+    want = []
+    for i, b in enumerate(batches):
+        s = rt.Session(rt.Graph(b), w, max_rounds=R)
+        o = s.sample(T, R, seed=seed + 1000003 * i + 1, early_exit=True, want_solved_fraction=False)
+        want.append((o["assignment"].cpu().numpy(), o["solved"].cpu().numpy() > 0))
+    for pooled, kw in ((True, {}), (False, {}), (True, {"arena_device_bytes": 1 << 20, "arena_pinned_bytes": 1 << 16})):
+        smp = StreamSampler(w, slots=2, n_steps=T, rounds=R, seed=seed, pooled=pooled, **kw)
+        got = {}
+        st = smp.run(batches, on_result=lambda i, b, a, sv: got.__setitem__(i, (a, sv)))
+        smp.close()
+        assert list(got) == list(range(len(batches)))                 # delivered in stream order
+        for i, (a, sv) in enumerate(want):
+            assert np.array_equal(got[i][0], a) and np.array_equal(got[i][1], sv), (pooled, i)
+            _host_check(batches[i], got[i][0], got[i][1])
+        assert st["batches"] == len(batches) and st["denoising_steps"] == T * len(batches)
+        assert len(st["host_setup_ms"]) == len(batches) and min(st["device_ms"]) > 0
+        if kw:
+            assert st["arena_growths"] >= 1
+
+
+# ------------------------------------------------------------------------------------------ config 5
+def test_config5_irregular_instance_matches_oracle_32_rounds(rt):
+    """A ~3k-variable irregular-degree instance (zipf_a=1.1: the busiest literals sit in well over a
+    thousand clauses) against the oracle for the full 32 rounds."""
+    from diffusionsat_amd.batch import make_batch
+    from diffusionsat_amd.instances import irregular_cnf
+    insts = [irregular_cnf(2800, 16000, seed=11, zipf_a=1.1)[:2]]
+    batch = make_batch(insts)
+    data = O.create_adj_matrices(insts)
+    deg = np.asarray(data["adjacency_matrix"].sum(axis=1)).ravel()
+    assert deg.max() > 1000
+    ws = oracle_weights(4)
+    rounds = 32
+    d = draws(batch.n_vars, rounds, seed=8)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.3), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32, trace=("logits", "per_graph_loss"))
+    s = rt.Session(rt.Graph(batch), rt.Weights(ws), max_rounds=rounds)
+    out = s.diffusion_step(0.3, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds, early_exit=False,
+                           want_logits=True, want_round_logits=True)
+    got = out["round_logits"].cpu().numpy()
+    for r in range(rounds):
+        assert np.abs(got[r] - ref["trace"]["logits"][r]).max() < 5e-4, r
+    srt = np.sort(ref["trace"]["per_graph_loss"][-1], axis=1)[0]
+    assert np.array_equal(out["best_map"].cpu().numpy(), ref["best_map"]) or srt[1] - srt[0] < 1e-3
+
+
+def test_config5_size_properties(rt, monkeypatch):
+    """BASELINE config 5 size (10 000 variables / 60 000 clauses, clause lengths 2..8, power-law literal
+    degrees up to thousands): bitwise run-to-run reproducibility, graph replay == eager, the fused
+    round kernels == the one-launch-per-layer path to 1e-4, and a T=4 sampler run whose solved flag
+    agrees with a host re-check."""
+    from diffusionsat_amd.batch import make_batch
+    from diffusionsat_amd.instances import irregular_cnf
+    batch = make_batch([irregular_cnf(10000, 60000, seed=5, zipf_a=1.1)[:2]])
+    assert batch.n_nodes == 80000
+    ws = oracle_weights(3)
+    rounds = 32
+    d = draws(batch.n_vars, rounds, seed=2)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, np.float32), d["uniform"])
+    args = (0.25, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]))
+    g, w = rt.Graph(batch), rt.Weights(ws)
+    s = rt.Session(g, w, max_rounds=rounds)
+    a = s.diffusion_step(*args, rounds=rounds, early_exit=True, want_logits=True)
+    b = s.diffusion_step(*args, rounds=rounds, early_exit=True, want_logits=True)
+    assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["prediction"], b["prediction"])
+    s.set_graph_replay(False)
+    c = s.diffusion_step(*args, rounds=rounds, early_exit=True, want_logits=True)
+    assert torch.equal(a["logits"], c["logits"])
+    monkeypatch.setenv("DSAT_FUSED", "0")
+    s0 = rt.Session(g, w, max_rounds=rounds)
+    monkeypatch.delenv("DSAT_FUSED")
+    e = s0.diffusion_step(*args, rounds=rounds, early_exit=True, want_logits=True)
+    assert torch.isfinite(a["logits"]).all()
+    assert (a["logits"] - e["logits"]).abs().max().item() < 1e-4
+    assert int(a["steps_taken"].item()) == int(e["steps_taken"].item()) == rounds - 1
+    out = s.sample(4, rounds, seed=3, early_exit=True)
+    _host_check(batch, out["assignment"].cpu().numpy(), out["solved"].cpu().numpy() > 0)
