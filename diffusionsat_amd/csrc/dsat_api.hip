@@ -315,6 +315,7 @@ static int graph_create_impl(dsat_arena* arena, hipStream_t st, const int32_t* c
     g->h_var_seg = vseg; g->h_cl_seg = cseg;
     g->h_c_rowptr.assign(clause_rowptr, clause_rowptr + C + 1);
     g->h_l_rowptr = l_rowptr;
+    g->h_l_clause = l_clause;
     hipError_t e = hipSuccess;
     if ((e = up(arena, st, &g->c_rowptr, clause_rowptr, (size_t)C + 1)) != hipSuccess ||
         (e = up(arena, st, &g->c_lit, c_lit.data(), (size_t)E)) != hipSuccess ||
@@ -552,11 +553,11 @@ extern "C" void dsat_weights_destroy(dsat_weights* w) {
 // ============================================================================ session
 enum KernelClass { KC_GEMM_QL1 = 0, KC_GEMM_Q, KC_GEMM_LIT, KC_GEMM_CLAUSE, KC_GEMM_UPDATE, KC_GEMM_OUT,
                    KC_CLAUSE_GATHER, KC_LITERAL_GATHER, KC_COLSUM, KC_PAIRNORM, KC_SELECT, KC_SATCHECK,
-                   KC_ROUND_P1, KC_ROUND_P2, KC_ROUND_P3, KC_SELECT_SAT, KC_MISC, KC_COUNT };
+                   KC_ROUND_P1, KC_ROUND_P2, KC_ROUND_P3, KC_SELECT_SAT, KC_MISC, KC_HEAVY, KC_SEGSUM2, KC_COUNT };
 static const char* kKernelClassNames[KC_COUNT] = {
     "gemm_query_lit_l1", "gemm_query", "gemm_lit", "gemm_clause", "gemm_update", "gemm_output",
     "clause_gather", "literal_gather", "pairnorm_colsum", "pairnorm_apply", "select", "sat_check",
-    "round_p1_var_query_lit", "round_p2_clause", "round_p3_var_update", "select_sat", "misc"};
+    "round_p1_var_query_lit", "round_p2_clause", "round_p3_var_update", "select_sat", "misc", "heavy_row_gather", "pairnorm_segsum2"};
 
 struct dsat_session {
     int device = -1;
@@ -586,6 +587,21 @@ struct dsat_session {
     float *sp = nullptr, *psum_v = nullptr, *psum_c = nullptr;
     int32_t *vmeta = nullptr, *vgseg = nullptr, *cmeta = nullptr, *cgseg = nullptr;
     std::vector<int32_t> h_vtile_seg, h_vgseg, h_ctile_seg, h_cgseg, h_vmeta, h_cmeta;
+    // heavy literal rows (kernels_round.hip, heavy_gather_kernel): empty unless the batch has any
+    int heavy_t = HEAVY_ROW_T;
+    int n_pieces = 0;
+    std::vector<int32_t> h_lrp_light, h_lcl_light, h_lhv, h_pieces;   // lhv / pieces: int2 pairs, flattened
+    int32_t *lrp_light = nullptr, *lcl_light = nullptr, *lhv = nullptr, *pieces = nullptr;
+    float* hpart = nullptr;
+    // level-2 PairNorm sums of graphs spread over many tiles (segsum2_kernel); empty unless needed
+    std::vector<int32_t> h_vgseg2, h_vchunks, h_cgseg2, h_cchunks;    // chunks: int2 pairs, flattened
+    int32_t *vgseg2 = nullptr, *vchunks = nullptr, *cgseg2 = nullptr, *cchunks = nullptr;
+    float *psum2_v = nullptr, *psum2_c = nullptr;
+    int n_vchunks = 0, n_cchunks = 0;
+    // select/SAT workgroups {graph, part, parts, 0}
+    std::vector<int32_t> h_sel_tab;
+    int32_t* sel_tab = nullptr;
+    int n_sel = 0, sel_zero = 0;
     long long* stamps = nullptr;   // [3][4096][8] when DSAT_STAMPS=1
     RoundArgs ra1, ra2, ra3;   // templates: per-launch fields (round, tail, ...) are patched in
     // graph replay
@@ -638,6 +654,24 @@ static void carve(dsat_session* s, Slab& sl) {
     s->sp = sl.take<float>((2 * N + 1) * F);
     s->psum_v = sl.take<float>(std::max<size_t>(s->h_vtile_seg.empty() ? 1 : s->h_vtile_seg.back(), 1) * F);
     s->psum_c = sl.take<float>(2 * std::max<size_t>(s->h_ctile_seg.empty() ? 1 : s->h_ctile_seg.back(), 1) * F);
+    if (s->n_pieces > 0) {
+        s->lrp_light = sl.take<int32_t>(s->h_lrp_light.size());
+        s->lcl_light = sl.take<int32_t>(std::max<size_t>(s->h_lcl_light.size(), 1));
+        s->lhv = sl.take<int32_t>(s->h_lhv.size());
+        s->pieces = sl.take<int32_t>(s->h_pieces.size());
+        s->hpart = sl.take<float>((size_t)s->n_pieces * 2 * F);
+    }
+    if (s->n_vchunks > 0) {
+        s->vgseg2 = sl.take<int32_t>(s->h_vgseg2.size());
+        s->vchunks = sl.take<int32_t>(s->h_vchunks.size());
+        s->psum2_v = sl.take<float>((size_t)s->n_vchunks * F);
+    }
+    if (s->n_cchunks > 0) {
+        s->cgseg2 = sl.take<int32_t>(s->h_cgseg2.size());
+        s->cchunks = sl.take<int32_t>(s->h_cchunks.size());
+        s->psum2_c = sl.take<float>((size_t)s->n_cchunks * F);
+    }
+    s->sel_tab = sl.take<int32_t>(s->h_sel_tab.size());
     s->vmeta = sl.take<int32_t>(s->h_vmeta.size());
     s->vgseg = sl.take<int32_t>(s->h_vgseg.size());
     s->cmeta = sl.take<int32_t>(s->h_cmeta.size());
@@ -756,6 +790,9 @@ static bool plan_round(dsat_session* s) {
     a.pgl = s->pgl; a.out_logits = s->out_logits; a.best = s->best; a.graph_unsat = s->graph_unsat;
     a.assign = s->assign;
     a.N = g->N; a.C = g->C; a.G = g->G;
+    a.vgseg2 = s->n_vchunks > 0 ? s->vgseg2 : nullptr; a.psum2_v = s->psum2_v;
+    a.cgseg2 = s->n_cchunks > 0 ? s->cgseg2 : nullptr; a.psum2_c = s->psum2_c;
+    a.sel_tab = s->sel_tab; a.n_sel = s->n_sel; a.sel_zero = s->sel_zero;
     a.V = s->V; a.Cs = s->Cs; a.q = s->q; a.sp = s->sp; a.lits = s->lits; a.closs4 = s->closs4;
     a.vla = s->vla; a.ncv = s->ncv; a.newv = s->newv; a.logits = s->logits;
     a.psum_v = s->psum_v; a.psum_c_rd = s->psum_c; a.psum_c_wr = s->psum_c; a.noisy = s->in_noisy; a.ctl = s->ctl;
@@ -806,6 +843,12 @@ static bool plan_round(dsat_session* s) {
         const auto& layers = w->mlp[DSAT_MLP_UPDATE_GATE];
         const int hid = max_hidden_pad(layers);
         r = a;
+        if (s->n_pieces > 0) {
+            r.l_rowptr = s->lrp_light;
+            r.l_clause = s->lcl_light;
+            r.l_hv = reinterpret_cast<const int2*>(s->lhv);
+            r.hpart = s->hpart;
+        }
         r.mupd = make_chain(layers, 1);
         r.ld_x = 4 * F + AUX_W + 8;
         r.ld_a = r.ld_b = hid + 8;
@@ -842,8 +885,66 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         s->p2_rb = rb;
         build_segments(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg);
         build_segments(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg);
-        build_tile_meta(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg, g->h_l_rowptr.data(), g->N,
-                        s->h_vmeta);
+        // level-2 PairNorm sums for graphs spread over many tiles
+        auto level2 = [](const std::vector<int32_t>& gseg, std::vector<int32_t>& gseg2, std::vector<int32_t>& chunks) {
+            const int G = (int)gseg.size() - 1;
+            gseg2.assign(G + 1, 0);
+            for (int g = 0; g < G; ++g) {
+                const int n = gseg[g + 1] - gseg[g];
+                int made = 0;
+                if (n > SEG2_MIN)
+                    for (int c = gseg[g]; c < gseg[g + 1]; c += SEG2_CHUNK, ++made) {
+                        chunks.push_back(c);
+                        chunks.push_back(std::min(c + SEG2_CHUNK, gseg[g + 1]));
+                    }
+                gseg2[g + 1] = gseg2[g] + made;
+            }
+            return (int)(chunks.size() / 2);
+        };
+        s->n_vchunks = level2(s->h_vgseg, s->h_vgseg2, s->h_vchunks);
+        s->n_cchunks = level2(s->h_cgseg, s->h_cgseg2, s->h_cchunks);
+        // select/SAT workgroups: one per graph, several for a graph with tens of thousands of clauses
+        for (int gi = 0; gi < g->G; ++gi) {
+            const int cg = g->h_cl_seg[gi + 1] - g->h_cl_seg[gi];
+            const int parts = std::max(1, std::min(64, (cg + SEL_PART_CLAUSES - 1) / SEL_PART_CLAUSES));
+            if (parts > 1) s->sel_zero = 1;
+            for (int p = 0; p < parts; ++p) {
+                const int32_t e[4] = {gi, p, parts, 0};
+                s->h_sel_tab.insert(s->h_sel_tab.end(), e, e + 4);
+            }
+        }
+        s->n_sel = (int)(s->h_sel_tab.size() / 4);
+        // heavy literal rows: a "light" copy of the literal->clause CSR with those rows emptied, the
+        // pieces heavy_gather_kernel sums, and per literal row where its pieces are
+        if (const char* ev = getenv("DSAT_HEAVY_T")) s->heavy_t = std::max(1, atoi(ev));
+        const int32_t* lrp = g->h_l_rowptr.data();
+        if (g->max_lit_deg > s->heavy_t) {
+            const size_t rows = 2 * (size_t)g->N;
+            s->h_lrp_light.assign(rows + 1, 0);
+            s->h_lhv.assign(2 * rows, 0);
+            for (size_t i = 0; i < rows; ++i) {
+                const int deg = lrp[i + 1] - lrp[i];
+                if (deg > s->heavy_t) {
+                    const int np = (deg + HEAVY_PIECE - 1) / HEAVY_PIECE;
+                    s->h_lhv[2 * i] = (int32_t)(s->h_pieces.size() / 2);
+                    s->h_lhv[2 * i + 1] = np;
+                    const int per = (deg + np - 1) / np;
+                    for (int p = 0; p < np; ++p) {
+                        s->h_pieces.push_back(lrp[i] + p * per);
+                        s->h_pieces.push_back(std::min(lrp[i] + (p + 1) * per, lrp[i + 1]));
+                    }
+                    s->h_lrp_light[i + 1] = s->h_lrp_light[i];
+                } else {
+                    s->h_lhv[2 * i] = -1;
+                    s->h_lcl_light.insert(s->h_lcl_light.end(), g->h_l_clause.begin() + lrp[i],
+                                          g->h_l_clause.begin() + lrp[i + 1]);
+                    s->h_lrp_light[i + 1] = s->h_lrp_light[i] + deg;
+                }
+            }
+            s->n_pieces = (int)(s->h_pieces.size() / 2);
+            lrp = s->h_lrp_light.data();
+        }
+        build_tile_meta(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg, lrp, g->N, s->h_vmeta);
         build_tile_meta(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg, g->h_c_rowptr.data(), -1,
                         s->h_cmeta);
     }
@@ -856,8 +957,11 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         if (rc != DSAT_OK) return rc;
         s->slab = static_cast<char*>(arena->take_dev(s->slab_bytes));
         // staging for the four tile / segment tables
-        const size_t meta_bytes = (s->h_vmeta.size() + s->h_vgseg.size() + s->h_cmeta.size() + s->h_cgseg.size()) *
-                                  sizeof(int32_t) + 4 * 64;
+        const size_t meta_bytes = (s->h_vmeta.size() + s->h_vgseg.size() + s->h_cmeta.size() + s->h_cgseg.size() +
+                                   s->h_lrp_light.size() + s->h_lcl_light.size() + s->h_lhv.size() +
+                                   s->h_pieces.size() + s->h_vgseg2.size() + s->h_vchunks.size() +
+                                   s->h_cgseg2.size() + s->h_cchunks.size() + s->h_sel_tab.size()) * sizeof(int32_t) +
+                                  16 * 64;
         char* stage = static_cast<char*>(arena->take_pin(meta_bytes));
         if (s->slab == nullptr || stage == nullptr) return arena_full(arena, "dsat_session_create_in");
         e = hipMemsetAsync(s->slab, 0, s->slab_bytes, st);
@@ -877,6 +981,21 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         if (e2 == hipSuccess) e2 = cp(s->vgseg, s->h_vgseg);
         if (e2 == hipSuccess) e2 = cp(s->cmeta, s->h_cmeta);
         if (e2 == hipSuccess) e2 = cp(s->cgseg, s->h_cgseg);
+        if (e2 == hipSuccess && s->n_pieces > 0) {
+            e2 = cp(s->lrp_light, s->h_lrp_light);
+            if (e2 == hipSuccess) e2 = cp(s->lcl_light, s->h_lcl_light);
+            if (e2 == hipSuccess) e2 = cp(s->lhv, s->h_lhv);
+            if (e2 == hipSuccess) e2 = cp(s->pieces, s->h_pieces);
+        }
+        if (e2 == hipSuccess && s->n_vchunks > 0) {
+            e2 = cp(s->vgseg2, s->h_vgseg2);
+            if (e2 == hipSuccess) e2 = cp(s->vchunks, s->h_vchunks);
+        }
+        if (e2 == hipSuccess && s->n_cchunks > 0) {
+            e2 = cp(s->cgseg2, s->h_cgseg2);
+            if (e2 == hipSuccess) e2 = cp(s->cchunks, s->h_cchunks);
+        }
+        if (e2 == hipSuccess) e2 = cp(s->sel_tab, s->h_sel_tab);
         if (e2 != hipSuccess) {
             (void)hipStreamDestroy(s->cap_stream);
             return hip_fail(e2, "segment upload", __FILE__, __LINE__);
@@ -900,6 +1019,21 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         if (e2 == hipSuccess) e2 = cp(s->vgseg, s->h_vgseg);
         if (e2 == hipSuccess) e2 = cp(s->cmeta, s->h_cmeta);
         if (e2 == hipSuccess) e2 = cp(s->cgseg, s->h_cgseg);
+        if (e2 == hipSuccess && s->n_pieces > 0) {
+            e2 = cp(s->lrp_light, s->h_lrp_light);
+            if (e2 == hipSuccess) e2 = cp(s->lcl_light, s->h_lcl_light);
+            if (e2 == hipSuccess) e2 = cp(s->lhv, s->h_lhv);
+            if (e2 == hipSuccess) e2 = cp(s->pieces, s->h_pieces);
+        }
+        if (e2 == hipSuccess && s->n_vchunks > 0) {
+            e2 = cp(s->vgseg2, s->h_vgseg2);
+            if (e2 == hipSuccess) e2 = cp(s->vchunks, s->h_vchunks);
+        }
+        if (e2 == hipSuccess && s->n_cchunks > 0) {
+            e2 = cp(s->cgseg2, s->h_cgseg2);
+            if (e2 == hipSuccess) e2 = cp(s->cchunks, s->h_cchunks);
+        }
+        if (e2 == hipSuccess) e2 = cp(s->sel_tab, s->h_sel_tab);
         if (e2 != hipSuccess) {
             (void)hipFree(s->slab);
             return hip_fail(e2, "segment upload", __FILE__, __LINE__);
@@ -1214,6 +1348,7 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
     hipError_t lerr = hipSuccess;   // first launch failure of the sequence
     auto note = [&](hipError_t e) { if (lerr == hipSuccess && e != hipSuccess) lerr = e; };
     const dsat_tap* tap = s->tap_on ? &s->tap : nullptr;
+    const int* done_flag = early_exit ? &s->ctl->done : nullptr;
     const size_t nf = (size_t)s->g->N * F, cf = (size_t)s->g->C * F;
     auto tap_copy = [&](float* dst, const float* src, size_t n) {
         if (dst != nullptr && n > 0) note(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1239,8 +1374,8 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         if (r == rounds) {
             // R15-R17 of the last round (with early exit the earlier rounds' run inside P2)
             L.run(KC_SELECT_SAT, [&] {
-                launch_select_sat(s->g, s->logits, s->ctl, s->pgl, s->best, s->out_logits, s->assign,
-                                  s->graph_unsat, r - 1, early_exit, st);
+                launch_select_sat(s->g, s->sel_tab, s->n_sel, s->logits, s->ctl, s->pgl, s->best, s->out_logits,
+                                  s->assign, s->graph_unsat, r - 1, early_exit, st);
             });
             break;
         }
@@ -1257,13 +1392,28 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         a3.tap_grad = tapped ? tap->variables_grad : nullptr;
         a3.tap_vloss = tapped ? tap->variables_loss : nullptr;
         L.run(KC_ROUND_P2, [&] { note(launch_round_p2(a2, s->p2_rb, st)); });
+        if (s->n_cchunks > 0)   // level-2 sums of the clause column sums P2 just wrote (large graphs)
+            L.run(KC_SEGSUM2, [&] {
+                note(launch_segsum2(reinterpret_cast<const int2*>(s->cchunks), s->n_cchunks, a2.psum_c_wr, s->psum2_c,
+                                    done_flag, st));
+            });
         if (tapped) {
             tap_copy(tap->clauses_loss4, s->closs4, cf);
             tap_copy(tap->variables_loss_all, s->vla, cf);
             tap_copy(tap->new_clause_value, s->ncv, cf);
         }
         if (tap != nullptr && r == tap->round + 1) tap_copy(tap->clause_state, s->Cs, cf);   // R10 of the tapped round
+        if (s->n_pieces > 0)   // sums of the heavy literal rows, spread over the chip (reads P2's closs4 / vla)
+            L.run(KC_HEAVY, [&] {
+                note(launch_heavy_gather(reinterpret_cast<const int2*>(s->pieces), s->n_pieces, s->g->l_clause,
+                                         s->closs4, s->vla, s->g->C, s->hpart, done_flag, st));
+            });
         L.run(KC_ROUND_P3, [&] { note(launch_round_p3(a3, st)); });
+        if (s->n_vchunks > 0)
+            L.run(KC_SEGSUM2, [&] {
+                note(launch_segsum2(reinterpret_cast<const int2*>(s->vchunks), s->n_vchunks, s->psum_v, s->psum2_v,
+                                    done_flag, st));
+            });
         if (tapped) tap_copy(tap->new_variables, s->newv, nf);
     }
     if (lerr != hipSuccess) return hip_fail(lerr, "fused round launch", __FILE__, __LINE__);

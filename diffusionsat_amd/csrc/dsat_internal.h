@@ -85,6 +85,7 @@ struct dsat_graph {
     float* rev_w = nullptr;       // [C]   rsqrt(max(clause_len,1))        (:197)
     std::vector<int32_t> h_var_seg, h_cl_seg;
     std::vector<int32_t> h_c_rowptr, h_l_rowptr;   // host copies for the per-tile records
+    std::vector<int32_t> h_l_clause;               // host copy of the literal->clause lists (heavy-row split)
 };
 
 namespace dsat {
@@ -197,6 +198,19 @@ struct RoundArgs {
     int check_done;        // early exit armed: skip when ctl->done
     int tail;              // P1 only: run the PairNorm + output-MLP part and stop
     long long* stamps;     // diagnostics (DSAT_STAMPS=1): [tile][8] shader-clock stamps, else nullptr
+    // Heavy literal rows (more than HEAVY_ROW_T clauses; irregular-degree graphs): P3 walks the "light"
+    // CSR in l_rowptr / l_clause, in which those rows are empty, and adds the row's partial sums that
+    // heavy_gather_kernel left in hpart ([piece][closs4 | vla][128]) in piece order.
+    const int2* l_hv;      // [2N] {first piece, pieces} or {-1, 0}; nullptr when the batch has no heavy row
+    const float* hpart;
+    // Graphs spread over more than SEG2_MIN tiles: their per-tile column sums are pre-summed in chunks
+    // (segsum2_kernel); [gseg2[g], gseg2[g+1]) is the graph's range in psum2 (empty for other graphs).
+    const int32_t *vgseg2, *cgseg2;   // nullptr when the batch has no such graph
+    const float *psum2_v, *psum2_c;
+    // select/SAT workgroups: {graph, part, parts, 0} each (large graphs are cut into several parts)
+    const int32_t* sel_tab;
+    int n_sel;
+    int sel_zero;          // P3: zero graph_unsat (some graph has several select parts)
     // debug taps (dsat_session_set_tap; nullptr in every production launch): values that only exist in
     // LDS on the fused path, written out by the tile that owns them
     float* tap_cmsg;       // P2: clause_messages [C,128]                       (query_sat.py:255-256)
@@ -223,9 +237,21 @@ constexpr int ROUND_TPW_CAP = ROUND_NWAVES >= 16 ? 2 : 8;   // tiles per wave th
 hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st);
 hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st);
 hipError_t launch_round_p3(const RoundArgs& a, hipStream_t st);
-void launch_select_sat(const dsat_graph* g, const float* logits, Ctl* ctl, float* pgl, int32_t* best,
-                       float* out_logits, uint8_t* assign, int32_t* graph_unsat, int round, int set_done,
-                       hipStream_t st);
+// Rows of the literal->clause CSR longer than this are "heavy": split into pieces of at most
+// HEAVY_PIECE entries, each summed by one workgroup of heavy_gather_kernel (spread over the whole
+// chip) instead of serially by the one half-wave that owns the row in its P3 tile.
+constexpr int HEAVY_ROW_T = 32;
+constexpr int HEAVY_PIECE = 512;
+hipError_t launch_heavy_gather(const int2* pieces, int n_pieces, const int32_t* l_clause, const float* closs4,
+                               const float* vla, int C, float* hpart, const int* done, hipStream_t st);
+void launch_select_sat(const dsat_graph* g, const int32_t* sel_tab, int n_sel, const float* logits, Ctl* ctl,
+                       float* pgl, int32_t* best, float* out_logits, uint8_t* assign, int32_t* graph_unsat,
+                       int round, int set_done, hipStream_t st);
+constexpr int SEG2_MIN = 32;      // graphs with more PairNorm segments than this get level-2 sums
+constexpr int SEG2_CHUNK = 64;    // level-1 segments per level-2 sum
+constexpr int SEL_PART_CLAUSES = 4096;   // clauses per select/SAT workgroup of a large graph
+hipError_t launch_segsum2(const int2* chunks, int n_chunks, const float* psum, float* psum2, const int* done,
+                          hipStream_t st);
 
 // closs_out = closs_scale * exp(-S)
 void launch_clause_gather(const dsat_graph* g, const float* q, const float* lits,

@@ -31,6 +31,16 @@ constexpr int NT = ROUND_NWAVES * 64;
         if ((a).stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096)                 \
             (a).stamps[blockIdx.x * 8 + (k)] = clock64();                                   \
     } while (0)
+// Slot 7 of a tile's stamps: the 100 MHz real-time counter's ticks between the tile's first and last
+// stamp, so that tools/stamps.py can turn shader-clock cycles into time and report the clock the
+// kernel actually ran at (MI355X_MICROARCH.md, DVFS give-back item 6).
+#define DSAT_STAMP_RT_BEGIN(a) \
+    const unsigned long long _rt0 = ((a).stamps != nullptr && threadIdx.x == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull
+#define DSAT_STAMP_RT_END(a)                                                              \
+    do {                                                                                  \
+        if ((a).stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096)                 \
+            (a).stamps[blockIdx.x * 8 + 7] = (long long)(__builtin_amdgcn_s_memrealtime() - _rt0); \
+    } while (0)
 constexpr int LDS_FLOATS = 40960;   // 160 KiB static (see kernels_chain.hip on dynamic LDS)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -105,7 +115,8 @@ __device__ __forceinline__ int both_arrived(int done, const TileMetaDev& m) {
 template <int BM>
 __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileMetaDev& tm,
                                               const int32_t* __restrict__ seg, const int32_t* __restrict__ gseg,
-                                              const float* __restrict__ psum, const float* __restrict__ x,
+                                              const float* __restrict__ psum, const int32_t* __restrict__ gseg2,
+                                              const float* __restrict__ psum2, const float* __restrict__ x,
                                               float* __restrict__ state, bool first, float* sState, int ldS,
                                               float* sLogit, int ldL, float* sMean, int tid) {
     constexpr int ROWS = (BM + NT / 32 - 1) / (NT / 32);
@@ -141,8 +152,14 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
         const int lo = max(s0, tile_lo), hi = min(s1, tile_hi);
         if (lo >= hi) continue;   // wave-uniform
         if (tid < F) {
+            // a graph spread over many tiles has had its segments pre-summed in chunks (segsum2_kernel)
+            const float* ps = psum;
+            if (gseg2 != nullptr) {
+                const int b0 = gseg2[g], b1 = gseg2[g + 1];
+                if (b1 > b0) { ps = psum2; gs0 = b0; gs1 = b1; }
+            }
             float m = 0.f;
-            for (int sgi = gs0; sgi < gs1; ++sgi) m += psum[(size_t)sgi * F + tid];
+            for (int sgi = gs0; sgi < gs1; ++sgi) m += ps[(size_t)sgi * F + tid];
             sMean[tid] = m * (1.f / (float)(s1 - s0));
         }
         __syncthreads();
@@ -336,7 +353,8 @@ __device__ __forceinline__ bool stage_csr(const int32_t* __restrict__ rowptr, co
 
 // R15-R17 for one graph (forward declaration; defined with the stand-alone kernel below)
 template <int NTH>
-__device__ void select_sat_body(int g, int ngraphs, const int32_t* __restrict__ vseg,
+__device__ void select_sat_body(int blk, int nblocks, const int32_t* __restrict__ sel_tab,
+                                const int32_t* __restrict__ vseg,
                                 const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
                                 const int32_t* __restrict__ c_lit, const float* __restrict__ logits,
                                 Ctl* __restrict__ ctl, float* __restrict__ pgl, int32_t* __restrict__ best,
@@ -356,8 +374,14 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
         const int lo = max(s0, lo0), hi = min(s1, hi0);
         if (lo >= hi) continue;
         if (tid < F) {
+            const float* ps = a.psum_c_rd;
+            int gs0 = a.cgseg[g], gs1 = a.cgseg[g + 1];
+            if (a.cgseg2 != nullptr) {
+                const int b0 = a.cgseg2[g], b1 = a.cgseg2[g + 1];
+                if (b1 > b0) { ps = a.psum2_c; gs0 = b0; gs1 = b1; }
+            }
             float m = 0.f;
-            for (int sgi = a.cgseg[g]; sgi < a.cgseg[g + 1]; ++sgi) m += a.psum_c_rd[(size_t)sgi * F + tid];
+            for (int sgi = gs0; sgi < gs1; ++sgi) m += ps[(size_t)sgi * F + tid];
             sMean[tid] = m * (1.f / (float)(s1 - s0));
         }
         __syncthreads();
@@ -410,12 +434,13 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     float* sMean = smem + a.off_mean;
     const int ldx = a.ld_x, ldv = F + 8;
 
+    DSAT_STAMP_RT_BEGIN(a);
     DSAT_STAMP(a, 0);
     if (tid < BM) {   // aux columns of v1 for this round (independent of everything else)
         const int n = tile_lo + tid;
         load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N && !a.tail);
     }
-    pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.newv, a.V, a.round == 0, sX, ldx, sVlog,
+    pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V, a.round == 0, sX, ldx, sVlog,
                       ldv, sMean, tid);
     DSAT_STAMP(a, 1);
 
@@ -465,6 +490,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
         });
     }
     DSAT_STAMP(a, 4);
+    DSAT_STAMP_RT_END(a);
 }
 
 // ------------------------------------------------------------------------------------- P2
@@ -485,7 +511,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
     const TileMetaDev tm = load_meta(a.cmeta, tile);
     if (both_arrived(done, tm) != 0) return;
     if (extra) {
-        select_sat_body<NT>(blockIdx.x - tiles, a.G, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
+        select_sat_body<NT>(blockIdx.x - tiles, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
                             a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, N, a.round - 1, a.check_done,
                             smem);
         return;
@@ -498,6 +524,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
     float* sMean = smem + a.off_mean;
     const int ldx = a.ld_x;
 
+    DSAT_STAMP_RT_BEGIN(a);
     DSAT_STAMP(a, 0);
     // the clause rows' literal lists -> LDS (sA is free until the first layer writes it)
     int* sPtr = reinterpret_cast<int*>(sA);
@@ -515,7 +542,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
         }
         __syncthreads();
     } else {
-        pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.ncv, a.Cs, a.round == 0, sX, ldx,
+        pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.cgseg2, a.psum2_c, a.ncv, a.Cs, a.round == 0, sX, ldx,
                           nullptr, 0, sMean, tid);   // its barriers also publish sPtr / sIdx
     }
     DSAT_STAMP(a, 1);
@@ -614,6 +641,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
         DSAT_STAMP(a, 3);
         tile_colsums<BM>(tile_lo, C, tm, a.cl_seg, a.psum_c_wr, stage, lds, sMean, tid);
         DSAT_STAMP(a, 4);
+        DSAT_STAMP_RT_END(a);
     }
 }
 
@@ -632,6 +660,8 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
     const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
     const TileMetaDev tm = load_meta(a.vmeta, tile);
     if (both_arrived(done, tm) != 0) return;
+    if (a.sel_zero && blockIdx.x == 0)   // multi-part select adds its counts up: start the next one from zero
+        for (int g = tid; g < a.G; g += NT) a.graph_unsat[g] = 0;
     const int tile_lo = tile * BM;
     const int tile_hi = min(tile_lo + BM, N);
     float* sX = smem + a.off_x;
@@ -641,6 +671,7 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
     const int ldx = a.ld_x;
     // unit = [variables_grad | variables | aux | loss_pos | loss_neg]        (query_sat.py:277)
     constexpr int OFF_V = F, OFF_AUX = 2 * F, OFF_POS = 2 * F + AUX_W, OFF_NEG = 3 * F + AUX_W;
+    DSAT_STAMP_RT_BEGIN(a);
     DSAT_STAMP(a, 0);
     DSAT_STAMP(a, 4);
     {   // R4 + R11: one wave per variable, half 0 = literal +v, half 1 = literal -v
@@ -658,13 +689,16 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
         // rows that do not depend on the lists: q (half 0) and the carried state (half 1)
         float4 rowv[PASSES], qrow[PASSES];
         float wdeg[PASSES], wv[PASSES];
+        int2 hv[PASSES];
 #pragma unroll
         for (int u = 0; u < PASSES; ++u) {
             const int v = tile_lo + wave + u * ROUND_NWAVES;
             rowv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             qrow[u] = rowv[u];
             wdeg[u] = 0.f; wv[u] = 0.f;
+            hv[u] = make_int2(-1, 0);
             if (v < N) {
+                if (a.l_hv != nullptr) hv[u] = a.l_hv[v + half * N];
                 qrow[u] = ld4(a.q + (size_t)v * F + sub * 4);
                 if (half == 1) rowv[u] = ld4(a.V + (size_t)v * F + sub * 4);
                 wdeg[u] = a.deg_w[v + half * N];
@@ -733,6 +767,17 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
                     VL[u].x += vv[u][j].x; VL[u].y += vv[u][j].y; VL[u].z += vv[u][j].z; VL[u].w += vv[u][j].w;
                 }
         }
+        if (a.l_hv != nullptr) {   // heavy rows: their sums come in pieces from heavy_gather_kernel
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u) {
+                for (int p = 0; p < hv[u].y; ++p) {
+                    const float* hp = a.hpart + ((size_t)(hv[u].x + p) * 2) * F + sub * 4;
+                    const float4 m4 = ld4(hp), v4 = ld4(hp + F);
+                    M[u].x += m4.x; M[u].y += m4.y; M[u].z += m4.z; M[u].w += m4.w;
+                    VL[u].x += v4.x; VL[u].y += v4.y; VL[u].z += v4.z; VL[u].w += v4.w;
+                }
+            }
+        }
         DSAT_STAMP(a, 6);
         // the last part of the tile preparation runs inside the chain, after it has asked for
         // its first weight fragments (run_chain's `prep`), and the chain takes the barrier
@@ -783,6 +828,80 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
         DSAT_STAMP(a, 2);
         tile_colsums<BM>(tile_lo, N, tm, a.var_seg, a.psum_v, stage, lds, sPart, tid);
         DSAT_STAMP(a, 3);
+        DSAT_STAMP_RT_END(a);
+    }
+}
+
+// ------------------------------------------------------------------------------------- PairNorm, level 2
+// A graph spread over many tiles (one 10 000-variable formula = 625 variable tiles) would have every
+// consumer tile add up hundreds of per-tile column sums.  For such graphs the sums are first combined
+// in chunks of SEG2_CHUNK: one workgroup per chunk, eight row groups added in a fixed order.
+__global__ __launch_bounds__(1024) void segsum2_kernel(const int2* __restrict__ chunks, const float* __restrict__ psum,
+                                                       float* __restrict__ psum2, const int* __restrict__ done) {
+    if (done != nullptr && *done != 0) return;
+    __shared__ float red[8][F];
+    const int c = threadIdx.x & (F - 1), grp = threadIdx.x >> 7;
+    const int2 ch = chunks[blockIdx.x];
+    float acc = 0.f;
+    for (int r = ch.x + grp; r < ch.y; r += 8) acc += psum[(size_t)r * F + c];
+    red[grp][c] = acc;
+    __syncthreads();
+    if (threadIdx.x < F) {
+        float t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][c];
+        psum2[(size_t)blockIdx.x * F + c] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------- heavy rows
+// One workgroup (8 half-waves) per piece of a heavy literal row: half-wave h sums entries
+// [e_lo + h*per, e_lo + (h+1)*per) of the piece (closs4 and vla rows of those clauses, in list
+// order), the eight sums are combined in half-wave order: deterministic, no atomics.
+__global__ __launch_bounds__(256) void heavy_gather_kernel(const int2* __restrict__ pieces,
+                                                           const int32_t* __restrict__ l_clause,
+                                                           const float* __restrict__ closs4,
+                                                           const float* __restrict__ vla, int C,
+                                                           float* __restrict__ hpart, const int* __restrict__ done) {
+    if (done != nullptr && *done != 0) return;
+    __shared__ float4 red[8][2][32];
+    constexpr int GJ = 4;
+    const int sub = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    const int2 pc = pieces[blockIdx.x];
+    const int len = pc.y - pc.x;
+    const int per = ((len + 7) / 8 + GJ - 1) / GJ * GJ;
+    const int e0 = pc.x + hw * per, e1 = min(e0 + per, pc.y);
+    float4 M = make_float4(0.f, 0.f, 0.f, 0.f), VL = M;
+    const unsigned zrow = (unsigned)C;   // the all-zero pad row of closs4 / vla
+    for (int e = e0; e < e1; e += GJ) {
+        unsigned ci[GJ];
+        float4 cv[GJ], vv[GJ];
+#pragma unroll
+        for (int j = 0; j < GJ; ++j) ci[j] = e + j < e1 ? (unsigned)l_clause[e + j] : zrow;
+#pragma unroll
+        for (int j = 0; j < GJ; ++j) {
+            const unsigned o = ci[j] * (unsigned)F + (unsigned)sub * 4u;
+            cv[j] = ld4(closs4 + o);
+            vv[j] = ld4(vla + o);
+        }
+#pragma unroll
+        for (int j = 0; j < GJ; ++j) {
+            M.x += cv[j].x; M.y += cv[j].y; M.z += cv[j].z; M.w += cv[j].w;
+            VL.x += vv[j].x; VL.y += vv[j].y; VL.z += vv[j].z; VL.w += vv[j].w;
+        }
+    }
+    red[hw][0][sub] = M;
+    red[hw][1][sub] = VL;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int arr = threadIdx.x >> 5;
+        float4 t = red[0][arr][sub];
+#pragma unroll
+        for (int h = 1; h < 8; ++h) {
+            const float4 u = red[h][arr][sub];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        st4(hpart + ((size_t)blockIdx.x * 2 + arr) * F + sub * 4, t);
     }
 }
 
@@ -795,8 +914,16 @@ __device__ __forceinline__ float bern_kl(float a, float b) {
     return a * (logf(a) - logf(b)) + (1.f - a) * (log1pf(-a) - log1pf(-b));
 }
 
+// One workgroup per entry of sel_tab = {graph, part, parts}.  A graph of ordinary size is one part.  A
+// large graph (tens of thousands of clauses: its clause check would be one workgroup's serial chain
+// of dependent loads) is cut into `parts` workgroups: every part recomputes the graph's eight loss
+// sums in the same order (same argmin everywhere, no exchange), then writes the selected logits /
+// bits of ITS slice of the variables and checks ITS slice of the clauses, taking literal values
+// straight from the logits, so no part waits for another's bits.  Unsatisfied-clause counts meet in
+// graph_unsat (integer atomics; zeroed by P3 before every select when parts > 1).
 template <int NTH>
-__device__ void select_sat_body(int g, int ngraphs, const int32_t* __restrict__ vseg,
+__device__ void select_sat_body(int blk, int nblocks, const int32_t* __restrict__ sel_tab,
+                                const int32_t* __restrict__ vseg,
                                 const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
                                 const int32_t* __restrict__ c_lit, const float* __restrict__ logits,
                                 Ctl* __restrict__ ctl, float* __restrict__ pgl, int32_t* __restrict__ best,
@@ -807,6 +934,7 @@ __device__ void select_sat_body(int g, int ngraphs, const int32_t* __restrict__ 
     int* s_best = reinterpret_cast<int*>(sred + NTH * (LOGIT_MAPS + 1));
     int* s_unsat = s_best + 1;
     const int tid = threadIdx.x;
+    const int g = sel_tab[4 * blk], part = sel_tab[4 * blk + 1], parts = sel_tab[4 * blk + 2];
     const int v0 = vseg[g], v1 = vseg[g + 1];
     const float t = powf(ctl->noise_scale, 0.5f);
     const float tl = fminf(t + 0.01f, 1.f);
@@ -847,40 +975,61 @@ __device__ void select_sat_body(int g, int ngraphs, const int32_t* __restrict__ 
         const float inv = 1.f / (float)(v1 - v0);
         int bi = 0;
         float bv = red[0][0] * inv;
-        pgl[g * LOGIT_MAPS] = bv;
+        if (part == 0) pgl[g * LOGIT_MAPS] = bv;
         for (int k = 1; k < LOGIT_MAPS; ++k) {
             const float x = red[0][k] * inv;
-            pgl[g * LOGIT_MAPS + k] = x;
+            if (part == 0) pgl[g * LOGIT_MAPS + k] = x;
             if (x < bv) { bv = x; bi = k; }   // first minimum wins, as TF's CPU ArgMin
         }
-        best[g] = bi;
+        if (part == 0) best[g] = bi;
         *s_best = bi;
     }
     __syncthreads();
     const int bi = *s_best;
-    for (int v = v0 + tid; v < v1; v += NTH) {
-        const float x = logits[(size_t)v * LOGIT_MAPS + bi];
-        out_logits[v] = x;
-        assign[v] = (uint8_t)rintf(sigmoid_f(x));   // tf.round(tf.sigmoid(.)), half-to-even
-    }
-    __syncthreads();   // this workgroup's assign[] stores are visible to its own loads (same CU L1)
-    int unsat = 0;
-    for (int c = cseg[g] + tid; c < cseg[g + 1]; c += NTH) {
-        bool sat = false;
-        for (int e = rowptr[c]; e < rowptr[c + 1]; ++e) {
-            const int l = c_lit[e];
-            sat = sat || (l < N ? (assign[l] != 0) : (assign[l - N] == 0));
+    {   // this part's slice of the variables
+        const int per = (v1 - v0 + parts - 1) / parts;
+        const int a0 = v0 + part * per, a1 = min(a0 + per, v1);
+        for (int v = a0 + tid; v < a1; v += NTH) {
+            const float x = logits[(size_t)v * LOGIT_MAPS + bi];
+            out_logits[v] = x;
+            assign[v] = (uint8_t)rintf(sigmoid_f(x));   // tf.round(tf.sigmoid(.)), half-to-even
         }
-        unsat += sat ? 0 : 1;
+    }
+    int unsat = 0;
+    if (parts == 1) {
+        __syncthreads();   // this workgroup's assign[] stores are visible to its own loads (same CU L1)
+        for (int c = cseg[g] + tid; c < cseg[g + 1]; c += NTH) {
+            bool sat = false;
+            for (int e = rowptr[c]; e < rowptr[c + 1]; ++e) {
+                const int l = c_lit[e];
+                sat = sat || (l < N ? (assign[l] != 0) : (assign[l - N] == 0));
+            }
+            unsat += sat ? 0 : 1;
+        }
+    } else {   // this part's slice of the clauses; literal values recomputed from the logits
+        const int c0 = cseg[g], c1 = cseg[g + 1];
+        const int per = (c1 - c0 + parts - 1) / parts;
+        const int a0 = c0 + part * per, a1 = min(a0 + per, c1);
+        for (int c = a0 + tid; c < a1; c += NTH) {
+            bool sat = false;
+            for (int e = rowptr[c]; e < rowptr[c + 1]; ++e) {
+                const int l = c_lit[e];
+                const int v = l < N ? l : l - N;
+                const bool val = rintf(sigmoid_f(logits[(size_t)v * LOGIT_MAPS + bi])) != 0.f;
+                sat = sat || (l < N ? val : !val);
+            }
+            unsat += sat ? 0 : 1;
+        }
     }
     if (unsat) atomicAdd(s_unsat, unsat);
     __syncthreads();
     if (tid == 0) {
-        graph_unsat[g] = *s_unsat;
+        if (parts == 1) graph_unsat[g] = *s_unsat;
+        else if (*s_unsat) atomicAdd(&graph_unsat[g], *s_unsat);
         if (*s_unsat) atomicAdd(&ctl->unsat_total, *s_unsat);
         __threadfence();
         const int tk = atomicAdd(&ctl->ticket, 1);
-        if (tk == ngraphs - 1) {
+        if (tk == nblocks - 1) {
             const int total = atomicAdd(&ctl->unsat_total, 0);
             ctl->steps_taken = round;
             if (set_done && total == 0) ctl->done = 1;
@@ -891,13 +1040,14 @@ __device__ void select_sat_body(int g, int ngraphs, const int32_t* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void select_sat_kernel(
+    const int32_t* __restrict__ sel_tab,
     const int32_t* __restrict__ vseg, const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ c_lit, const float* __restrict__ logits, Ctl* __restrict__ ctl,
     float* __restrict__ pgl, int32_t* __restrict__ best, float* __restrict__ out_logits,
     uint8_t* __restrict__ assign, int32_t* __restrict__ graph_unsat, int N, int round, int set_done) {
     if (set_done && ctl->done != 0) return;
     __shared__ float sred[256 * (LOGIT_MAPS + 1) + 2];
-    select_sat_body<256>(blockIdx.x, gridDim.x, vseg, cseg, rowptr, c_lit, logits, ctl, pgl, best, out_logits,
+    select_sat_body<256>(blockIdx.x, gridDim.x, sel_tab, vseg, cseg, rowptr, c_lit, logits, ctl, pgl, best, out_logits,
                          assign, graph_unsat, N, round, set_done, sred);
 }
 
@@ -910,7 +1060,7 @@ hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st) {
 }
 hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {
     const int bm = 16 * rb;
-    const int tiles = (a.C + bm - 1) / bm + (a.s_enable ? a.G : 0);
+    const int tiles = (a.C + bm - 1) / bm + (a.s_enable ? a.n_sel : 0);
     if (tiles == 0) return hipSuccess;
     if (rb == 4) hipLaunchKernelGGL(round_p2_kernel<4>, dim3(tiles), dim3(NT), 0, st, a);
     else if (rb == 2) hipLaunchKernelGGL(round_p2_kernel<2>, dim3(tiles), dim3(NT), 0, st, a);
@@ -923,10 +1073,23 @@ hipError_t launch_round_p3(const RoundArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(round_p3_kernel, dim3(tiles), dim3(NT), 0, st, a);
     return hipGetLastError();
 }
-void launch_select_sat(const dsat_graph* g, const float* logits, Ctl* ctl, float* pgl, int32_t* best,
-                       float* out_logits, uint8_t* assign, int32_t* graph_unsat, int round, int set_done,
-                       hipStream_t st) {
-    hipLaunchKernelGGL(select_sat_kernel, dim3(g->G), dim3(256), 0, st, g->var_seg, g->cl_seg, g->c_rowptr,
+hipError_t launch_segsum2(const int2* chunks, int n_chunks, const float* psum, float* psum2, const int* done,
+                          hipStream_t st) {
+    if (n_chunks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(segsum2_kernel, dim3(n_chunks), dim3(1024), 0, st, chunks, psum, psum2, done);
+    return hipGetLastError();
+}
+hipError_t launch_heavy_gather(const int2* pieces, int n_pieces, const int32_t* l_clause, const float* closs4,
+                               const float* vla, int C, float* hpart, const int* done, hipStream_t st) {
+    if (n_pieces <= 0) return hipSuccess;
+    hipLaunchKernelGGL(heavy_gather_kernel, dim3(n_pieces), dim3(256), 0, st, pieces, l_clause, closs4, vla, C, hpart,
+                       done);
+    return hipGetLastError();
+}
+void launch_select_sat(const dsat_graph* g, const int32_t* sel_tab, int n_sel, const float* logits, Ctl* ctl,
+                       float* pgl, int32_t* best, float* out_logits, uint8_t* assign, int32_t* graph_unsat,
+                       int round, int set_done, hipStream_t st) {
+    hipLaunchKernelGGL(select_sat_kernel, dim3(n_sel), dim3(256), 0, st, sel_tab, g->var_seg, g->cl_seg, g->c_rowptr,
                        g->c_lit, logits, ctl, pgl, best, out_logits, assign, graph_unsat, g->N, round, set_done);
 }
 

@@ -202,3 +202,32 @@ def test_config5_size_properties(rt, monkeypatch):
     assert int(a["steps_taken"].item()) == int(e["steps_taken"].item()) == rounds - 1
     out = s.sample(4, rounds, seed=3, early_exit=True)
     _host_check(batch, out["assignment"].cpu().numpy(), out["solved"].cpu().numpy() > 0)
+
+
+def test_large_graph_select_parts_and_early_exit(rt):
+    """One formula large enough to be cut into several select/SAT workgroups (more than 4096 clauses),
+    spread over enough tiles for the level-2 PairNorm sums, with one literal in thousands of clauses:
+    every clause a tautology -> is_batch_sat fires in round 0 and the graph is reported solved; the
+    same formula plus the unit clauses x1, -x1 -> never exits, exactly one clause unsatisfied
+    whichever way x1 is rounded, graph not solved.  Eager and graph replay."""
+    from diffusionsat_amd.batch import make_batch
+    rng = np.random.default_rng(0)
+    n, m = 1500, 9000
+    taut = []
+    for _ in range(m):
+        v = int(rng.integers(2, n + 1))
+        w = int(rng.integers(2, n + 1))
+        taut.append([v, -v, w] if rng.random() < 0.5 else [-v, v, -w, 1])     # x1 sits in ~half the clauses
+    ws = oracle_weights(6)
+    for clauses, want_exit in ((taut, True), (taut + [[1], [-1]], False)):
+        batch = make_batch([(n, clauses)])
+        s = rt.Session(rt.Graph(batch), rt.Weights(ws), max_rounds=6)
+        noisy = _dev(np.tile(np.array([[1, 0]], np.float32), (n, 1)))
+        for replay in (False, True):
+            s.set_graph_replay(replay)
+            out = s.diffusion_step(0.5, noisy, rounds=6, early_exit=True, seed=3, step_index=1)
+            assert int(out["steps_taken"].item()) == (0 if want_exit else 5)
+            smp = s.sample(2, 6, seed=5, early_exit=True)
+            assert bool(smp["solved"].cpu().numpy()[0]) == want_exit
+            assert smp["solved_fraction"] == (1.0 if want_exit else 0.0)
+            _host_check(batch, smp["assignment"].cpu().numpy(), smp["solved"].cpu().numpy() > 0)

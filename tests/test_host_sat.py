@@ -84,3 +84,55 @@ def test_sr_ksat_follows_the_neurosat_construction():
     n2, more = I.sr_ksat(seed=1, min_vars=12, max_vars=12, solutions_multiplier=20)
     assert n2 == n and len(more) < len(few)
     assert len(_brute(n, more)) >= len(_brute(n, few)) >= 1
+
+
+def test_native_sr_generator_properties():
+    """dsat_host_gen_sr (the reference's data/k_sat.py:36-93 generator, natively): deterministic per seed,
+    every instance satisfiable, clauses reduced (no duplicates / subsumed clauses, literals sorted, order by
+    (length, lexicographic) as dimacs.reduce_clauses), sizes and widths in the distribution's range, and --
+    without clause removal -- negating the first literal of one clause back gives an UNSAT formula, i.e.
+    the instance sits right at the SAT/UNSAT boundary as NeuroSAT's SR(n) pairs do."""
+    from diffusionsat_amd.dimacs import DimacsFile
+    a, b = I.sr_ksat_native(11), I.sr_ksat_native(11)
+    assert a.n_vars == b.n_vars and np.array_equal(a.rowptr, b.rowptr) and np.array_equal(a.lits, b.lits)
+    assert not np.array_equal(a.lits, I.sr_ksat_native(12).lits)
+    ratios, widths = [], []
+    for seed in range(40):
+        x = I.sr_ksat_native(1000 + seed, solutions_multiplier=1.0)
+        n, cl = x.as_instance()
+        assert 30 <= n <= 100 and all(1 <= abs(l) <= n for c in cl for l in c)
+        assert I.solve(n, cl)[0] is True
+        df = DimacsFile(clauses=[list(c) for c in cl])
+        df.reduce_clauses()
+        assert df.clauses() == cl                                   # already reduced, same canonical order
+        # exactly one clause, with its first literal negated back, makes the formula unsatisfiable
+        flips = sum(I.solve(n, cl[:i] + [[-c[0]] + c[1:]] + cl[i + 1:])[0] is False
+                    for i, c in enumerate(cl) if len(c) >= 1)
+        assert flips >= 1
+        ratios.append(len(cl) / n)
+        widths.extend(len(c) for c in cl)
+    assert 3.5 < np.mean(ratios) < 7.0 and 3.5 < np.mean(widths) < 5.0 and min(widths) >= 1
+    # the reference's default multiplier (10) removes a few clauses: still satisfiable, fewer clauses
+    x1, x10 = I.sr_ksat_native(5, solutions_multiplier=1.0), I.sr_ksat_native(5, solutions_multiplier=10.0)
+    assert x10.n_vars == x1.n_vars and 0 < x1.n_clauses - x10.n_clauses < 40
+    assert I.solve(*x10.as_instance())[0] is True
+    # same distribution as the Python restatement (different random stream): clause/variable ratio
+    py = [I.sr_ksat(seed=s) for s in range(12)]
+    assert abs(np.mean([len(c) / n for n, c in py]) - np.mean(ratios)) < 1.0
+
+
+def test_compact_batches_equal_list_batches():
+    from diffusionsat_amd.batch import CompactInstance, batch_by_node_budget, make_batch
+    xs = [I.sr_ksat_native(50 + i, min_vars=5, max_vars=20) for i in range(12)]
+    b1, b2 = make_batch(xs), make_batch([x.as_instance() for x in xs])
+    for f in ("clause_rowptr", "clause_lits", "var_graph_id", "clause_graph_id", "variables_in_graph",
+              "clauses_in_graph"):
+        assert np.array_equal(getattr(b1, f), getattr(b2, f)), f
+    assert (b1.n_vars, b1.n_clauses, b1.n_graphs) == (b2.n_vars, b2.n_clauses, b2.n_graphs)
+    g1 = batch_by_node_budget(xs, 300)
+    g2 = batch_by_node_budget([x.as_instance() for x in xs], 300)
+    assert [[i.n_vars for i in g] for g in g1] == [[n for n, _ in g] for g in g2]
+    rt = CompactInstance.from_instance(xs[0].as_instance())
+    assert np.array_equal(rt.lits, xs[0].lits) and np.array_equal(rt.rowptr, xs[0].rowptr)
+    with pytest.raises(ValueError):
+        make_batch([CompactInstance(2, [0, 1], [3])])
