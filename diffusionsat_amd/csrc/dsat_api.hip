@@ -1361,6 +1361,7 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
     for (int r = 0; r <= rounds; ++r) {
         a1.round = r;
         a1.tail = r == rounds;
+        a1.stamps = a1.tail ? nullptr : s->ra1.stamps;   // diagnostics: keep the last FULL launch's phase stamps
         const size_t half = std::max<size_t>(s->h_ctile_seg.empty() ? 1 : s->h_ctile_seg.back(), 1) * F;
         // idle CUs of P1 finish the clause PairNorm of round r-1 (only worth it while the variable
         // tiles leave CUs idle; otherwise P2 does it in its prologue)

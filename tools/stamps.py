@@ -1,32 +1,116 @@
-"""Phase breakdown of the fused round kernels from in-kernel clock stamps (DSAT_STAMPS=1)."""
-import os, sys
-os.environ["DSAT_STAMPS"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import ctypes as C
-import numpy as np, torch
-from diffusionsat_amd import runtime, _lib, weights as W
-from diffusionsat_amd.batch import make_batch
-from diffusionsat_amd.instances import config2_instances
-batch = make_batch(config2_instances(31))
-s = runtime.Session(runtime.Graph(batch), runtime.Weights(W.glorot_weights(0)))
-s.set_graph_replay(False)
-s.sample(2, 32, seed=1, early_exit=True, want_solved_fraction=False)
-torch.cuda.synchronize()
-buf = (C.c_int64 * (3 * 4096 * 8))()
-_lib.check(_lib.load().dsat_session_read_stamps(s.handle, buf, 3 * 4096 * 8))
-st = np.frombuffer(buf, dtype=np.int64).reshape(3, 4096, 8)
-names = {0: ["pairnorm+aux", "out_mlp", "query_mlp", "lit_mlp"], 1: ["pairnorm", "gather", "clause_mlp", "colsums"],
-         2: ["gather", "update_mlp", "colsums"]}
-tiles = {0: (batch.n_vars + 15) // 16, 1: (batch.n_clauses + 63) // 64, 2: (batch.n_vars + 15) // 16}
-for k in range(3):
-    t = st[k, :tiles[k]]
-    nph = len(names[k])
-    d = np.diff(t[:, :nph + 1], axis=1).astype(np.float64)
-    tot = (t[:, nph] - t[:, 0]).astype(np.float64)
-    print("P%d: %d tiles; per-tile cycles median total %.0f (max %.0f)" % (k + 1, tiles[k], np.median(tot), tot.max()))
-    for i, nm in enumerate(names[k]):
-        print("    %-14s median %8.0f  max %8.0f cycles" % (nm, np.median(d[:, i]), d[:, i].max()))
-    if k == 2:   # finer stamps inside the P3 gather (slots 4..6), thread 0's view
-        for nm, lo, hi in (("  meta", 0, 4), ("  stage+rows", 4, 5), ("  neighbour loop", 5, 6), ("  finish", 6, 1)):
-            dd = (t[:, hi] - t[:, lo]).astype(np.float64)
-            print("    %-16s median %8.0f  max %8.0f cycles" % (nm, np.median(dd), dd.max()))
+"""Phase breakdown of the fused round kernels from in-kernel clock stamps (DSAT_STAMPS=1).
+
+On the GPU box (writes the raw stamps + the table; both are committed under profiles/):
+    python tools/stamps.py --config 2 --out profiles/r02_stamps_cfg2
+Anywhere (re-derives the table from a committed dump, no GPU needed):
+    python tools/stamps.py --from profiles/r02_stamps_cfg2.npz
+
+The stamps are `s_memtime` (shader clock) values taken by thread 0 of every workgroup at the phase
+boundaries of the LAST full launch of each kernel in a denoising step; slot 7 holds the 100 MHz
+real-time ticks between the tile's first and last stamp, which gives the clock the kernel ran at.
+Only a diagnostic session executes them (a session created with DSAT_STAMPS=1).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+PHASES = {
+    "round_p1": [("pairnorm+aux", 0, 1), ("out_mlp || query_mlp", 1, 3), ("lit_mlp", 3, 4)],
+    "round_p2": [("state rows / pairnorm", 0, 1), ("gather (R3,R5,R7)", 1, 2), ("clause_mlp", 2, 3),
+                 ("column sums", 3, 4)],
+    "round_p3": [("gather (R4,R11)", 0, 1), ("  meta + list staging + own rows", 0, 5), ("  neighbour loop", 5, 6),
+                 ("  closed form + tile write", 6, 1), ("update_mlp", 1, 2), ("column sums", 2, 3)],
+}
+LAST = {"round_p1": 4, "round_p2": 4, "round_p3": 3}
+# MFMA issue floor of one tile: 16x16x4 MFMAs per SIMD x 32 cycles (fused_common.h blocking)
+MFMA_FLOOR = {"round_p1": (4 * (9 * 32 + 32 * 32 + 32 * 16) + 4 * (8 * 8 + 8 * 1 + 9 * 10 + 10 * 8)) // 4 * 32,
+              "round_p2": 16 * (24 * 13 + 13 * 16) // 4 * 32,
+              "round_p3": 4 * (33 * 15 + 15 * 15 + 15 * 8) // 4 * 32}
+
+
+def collect(config, rounds):
+    os.environ["DSAT_STAMPS"] = "1"
+    import ctypes as C
+    import torch
+    from diffusionsat_amd import runtime, _lib, weights as W
+    from diffusionsat_amd.batch import make_batch
+    from diffusionsat_amd.instances import config2_instances, config3_instances, irregular_cnf
+    if config == 2:
+        insts = config2_instances(31)
+    elif config == 3:
+        insts = config3_instances(256)
+    else:
+        insts = [irregular_cnf(10000, 60000, seed=5)[:2]]
+    batch = make_batch(insts)
+    s = runtime.Session(runtime.Graph(batch), runtime.Weights(W.glorot_weights(0)), max_rounds=rounds)
+    s.set_graph_replay(False)
+    for _ in range(3):     # bring the clocks to their loaded state
+        s.sample(4, rounds, seed=1, early_exit=True, want_solved_fraction=False)
+    torch.cuda.synchronize()
+    buf = (C.c_int64 * (3 * 4096 * 8))()
+    _lib.check(_lib.load().dsat_session_read_stamps(s.handle, buf, 3 * 4096 * 8))
+    st = np.frombuffer(buf, dtype=np.int64).reshape(3, 4096, 8).copy()
+    tiles = [min(4096, (batch.n_vars + 15) // 16), min(4096, (batch.n_clauses + 63) // 64),
+             min(4096, (batch.n_vars + 15) // 16)]
+    return {"round_p1": st[0, :tiles[0]], "round_p2": st[1, :tiles[1]], "round_p3": st[2, :tiles[2]]}, \
+        {"config": config, "rounds": rounds, "n_vars": batch.n_vars, "n_clauses": batch.n_clauses,
+         "n_graphs": batch.n_graphs}
+
+
+def table(stamps, meta):
+    out = {"meta": meta, "kernels": {}}
+    lines = []
+    for k in ("round_p1", "round_p2", "round_p3"):
+        t = stamps[k].astype(np.float64)
+        tot = t[:, LAST[k]] - t[:, 0]
+        rt = t[:, 7]                                   # 100 MHz ticks over the same span
+        ok = rt > 0
+        ghz = float(np.median(tot[ok] / (rt[ok] * 10.0))) if ok.any() else float("nan")
+        floor = MFMA_FLOOR[k]
+        kk = {"tiles": int(t.shape[0]), "cycles_per_tile_median": float(np.median(tot)),
+              "cycles_per_tile_max": float(tot.max()), "clock_ghz_median": ghz,
+              "us_per_tile_median": float(np.median(tot)) / (ghz * 1e3) if ghz == ghz else None,
+              "mfma_issue_floor_cycles": floor, "mfma_issue_share": floor / float(np.median(tot)), "phases": {}}
+        lines.append("%s: %d tiles; median %.0f cycles per tile (max %.0f) at %.2f GHz = %.1f us; MFMA issue floor "
+                     "%d cycles = %.0f %%" % (k, t.shape[0], np.median(tot), tot.max(), ghz,
+                                              np.median(tot) / (ghz * 1e3), floor, 100 * floor / np.median(tot)))
+        for name, lo, hi in PHASES[k]:
+            d = t[:, hi] - t[:, lo]
+            kk["phases"][name.strip()] = {"median": float(np.median(d)), "max": float(d.max())}
+            lines.append("    %-34s median %8.0f  max %8.0f cycles  (%4.1f %%)" % (
+                name, np.median(d), d.max(), 100 * np.median(d) / np.median(tot)))
+        out["kernels"][k] = kk
+    return out, "\n".join(lines)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5])
+    ap.add_argument("--rounds", type=int, default=32)
+    ap.add_argument("--out", default=None, help="prefix: writes <prefix>.npz (raw stamps) and <prefix>.json (table)")
+    ap.add_argument("--from", dest="src", default=None, help="re-derive the table from a committed .npz dump")
+    a = ap.parse_args()
+    if a.src:
+        z = np.load(a.src, allow_pickle=False)
+        stamps = {k: z[k] for k in ("round_p1", "round_p2", "round_p3")}
+        meta = json.loads(str(z["meta"]))
+    else:
+        stamps, meta = collect(a.config, a.rounds)
+    res, text = table(stamps, meta)
+    print(text)
+    if a.out and not a.src:
+        np.savez_compressed(a.out + ".npz", meta=json.dumps(meta), **stamps)
+        with open(a.out + ".json", "w") as f:
+            json.dump(res, f, indent=1)
+        with open(a.out + ".txt", "w") as f:
+            f.write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()
