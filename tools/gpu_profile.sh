@@ -20,7 +20,7 @@ python tools/pmc_report.py $O/pmc_* > $O/pmc_counters.json 2> $O/pmc_report.err;
 python tools/stamps.py --config 2 --out $O/stamps_cfg2 > $O/stamps_cfg2.stdout 2>&1; echo "stamps rc=$?"
 cat $O/stamps_cfg2.stdout | tail -25
 find $O/stats -name "*kernel_stats.csv" | head -2
-head -6 $(find $O/stats -name "*kernel_stats.csv" | head -1)
+python tools/pmc_report.py --stats $O/stats/run_results.db | head -6
 python - <<PY
 import json
 d=json.load(open("$O/pmc_counters.json"))

@@ -22,19 +22,47 @@ KERNELS = {"round_p1_kernel": "round_p1", "round_p2_kernel": "round_p2", "round_
            "select_sat_kernel": "select_sat", "aux_kernel": "aux"}
 
 
+def rows_of(d):
+    """Counter rows of one pass directory: rocprofv3's CSV output, or its default rocpd SQLite database."""
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                yield row
+    for f in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
+        import sqlite3
+        db = sqlite3.connect(f)
+        q = ("select kernel_name, counter_name, value, vgpr_count, accum_vgpr_count, sgpr_count, lds_block_size, "
+             "workgroup_size from counters_collection")
+        for r in db.execute(q):
+            yield {"Kernel_Name": r[0], "Counter_Name": r[1], "Counter_Value": r[2], "VGPR_Count": r[3],
+                   "Accum_VGPR_Count": r[4], "SGPR_Count": r[5], "LDS_Block_Size": r[6], "Workgroup_Size": r[7]}
+        db.close()
+
+
+def kernel_stats(db_path):
+    """`rocprofv3 --kernel-trace --stats` summary of a rocpd database as CSV text (Name, Calls, ...)."""
+    import sqlite3
+    db = sqlite3.connect(db_path)
+    out = ['"Name","Calls","TotalDurationUs","AverageUs","Percentage"']
+    for r in db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+        out.append('"%s",%d,%.3f,%.3f,%.4f' % r)
+    return "\n".join(out) + "\n"
+
+
 def main(dirs):
+    if dirs and dirs[0] == "--stats":
+        sys.stdout.write(kernel_stats(dirs[1]))
+        return
     vals = {}
     for d in dirs:
-        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-            with open(f, newline="") as fh:
-                for row in csv.DictReader(fh):
-                    for k, nm in KERNELS.items():
-                        if k in row["Kernel_Name"]:
-                            vals.setdefault(nm, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-                            meta = vals[nm].setdefault("_meta", {})
-                            meta["vgpr"] = int(row["VGPR_Count"]); meta["agpr"] = int(row["Accum_VGPR_Count"])
-                            meta["sgpr"] = int(row["SGPR_Count"]); meta["lds_bytes"] = int(row["LDS_Block_Size"])
-                            meta["workgroup"] = int(row["Workgroup_Size"])
+        for row in rows_of(d):
+            for k, nm in KERNELS.items():
+                if k in row["Kernel_Name"]:
+                    vals.setdefault(nm, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                    meta = vals[nm].setdefault("_meta", {})
+                    meta["vgpr"] = int(row["VGPR_Count"]); meta["agpr"] = int(row["Accum_VGPR_Count"])
+                    meta["sgpr"] = int(row["SGPR_Count"]); meta["lds_bytes"] = int(row["LDS_Block_Size"])
+                    meta["workgroup"] = int(row["Workgroup_Size"])
     out = {"source": __doc__.strip().split("\n\n")[1].replace("\n", " "), "kernels": {}}
     for nm, cs in vals.items():
         k = {"registers": cs.pop("_meta", {})}
