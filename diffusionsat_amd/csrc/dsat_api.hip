@@ -598,6 +598,10 @@ struct dsat_session {
     int32_t *vgseg2 = nullptr, *vchunks = nullptr, *cgseg2 = nullptr, *cchunks = nullptr;
     float *psum2_v = nullptr, *psum2_c = nullptr;
     int n_vchunks = 0, n_cchunks = 0;
+    // P1 role B: 64-row tile records; 0 blocks = the 16-row tiles run the output / query pair themselves
+    std::vector<int32_t> h_vmeta4;
+    int32_t* vmeta4 = nullptr;
+    int pair_blocks = 0;
     // select/SAT workgroups {graph, part, parts, 0}
     std::vector<int32_t> h_sel_tab;
     int32_t* sel_tab = nullptr;
@@ -672,6 +676,7 @@ static void carve(dsat_session* s, Slab& sl) {
         s->psum2_c = sl.take<float>((size_t)s->n_cchunks * F);
     }
     s->sel_tab = sl.take<int32_t>(s->h_sel_tab.size());
+    s->vmeta4 = sl.take<int32_t>(s->h_vmeta4.size());
     s->vmeta = sl.take<int32_t>(s->h_vmeta.size());
     s->vgseg = sl.take<int32_t>(s->h_vgseg.size());
     s->cmeta = sl.take<int32_t>(s->h_cmeta.size());
@@ -813,7 +818,23 @@ static bool plan_round(dsat_session* s) {
         r.off_a = r.off_vlog + ROUND_BM_VAR * (F + 8);
         r.off_b = r.off_a + ROUND_BM_VAR * r.ld_a;
         r.off_mean = r.off_b + ROUND_BM_VAR * r.ld_b;
-        ok = ok && (r.off_mean + F <= LDS);
+        const int mean_floats = (ROUND_NWAVES * 64 / F + 1) * F;   // per-graph mean + one partial per thread group
+        ok = ok && (r.off_mean + mean_floats <= LDS);
+        // role B: 64-row tiles for the output / query pair (kernels_round.hip, round_p1_kernel)
+        r.mq4 = make_chain(w->mlp[DSAT_MLP_VARIABLES_QUERY], 4);
+        r.vmeta4 = s->vmeta4;
+        r.b_ld_a = max_hidden_pad(w->mlp[DSAT_MLP_VARIABLES_OUTPUT]) + 8;
+        r.b_ld_b = max_hidden_pad(w->mlp[DSAT_MLP_VARIABLES_QUERY]) + 8;
+        r.b_off_x = 0;
+        r.b_off_vlog = 64 * r.ld_x;
+        r.b_off_a = r.b_off_vlog + 64 * (F + 8);
+        r.b_off_b = r.b_off_a + 64 * r.b_ld_a;
+        r.b_off_mean = r.b_off_b + 64 * r.b_ld_b;
+        const bool fits = r.b_off_mean + mean_floats <= LDS;
+        const bool shapes = ROUND_NWAVES == 16 && r.mout.nlayers == 2 && r.mq.nlayers == 2 &&
+                            r.mout.static_half_id == CHAIN_H11 && r.mq.static_half_id == CHAIN_H21 &&
+                            r.mq4.static_id == CHAIN_11;
+        s->pair_blocks = (fits && shapes && getenv("DSAT_NO_PAIRB") == nullptr) ? (g->N + 63) / 64 : 0;
     }
     {   // P2: [X BMx392 | A | (B) | mean]
         RoundArgs& r = s->ra2;
@@ -822,7 +843,7 @@ static bool plan_round(dsat_session* s) {
         int rb = 4;
         for (; rb >= 1; rb >>= 1) {
             const int bm = 16 * rb;
-            const int need = bm * (3 * F + 8) + bm * (hid + 8) * (layers.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64;
+            const int need = bm * (3 * F + 8) + bm * (hid + 8) * (layers.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64 + F;
             if (need <= LDS) break;
         }
         ok = ok && rb >= 1;
@@ -837,6 +858,7 @@ static bool plan_round(dsat_session* s) {
         r.off_a = bm * r.ld_x;
         r.off_b = layers.size() > 2 ? r.off_a + bm * r.ld_a : r.off_a;
         r.off_mean = r.off_b + bm * r.ld_b;
+        ok = ok && (r.off_mean + (ROUND_NWAVES * 64 / F + 1) * F <= LDS);
     }
     {   // P3: [X 16x536 | A | B]
         RoundArgs& r = s->ra3;
@@ -856,7 +878,7 @@ static bool plan_round(dsat_session* s) {
         r.off_a = ROUND_BM_VAR * r.ld_x;
         r.off_b = r.off_a + ROUND_BM_VAR * r.ld_a;
         r.off_mean = r.off_b + ROUND_BM_VAR * r.ld_b;
-        ok = ok && (r.off_mean + ROUND_NWAVES * 64 <= LDS);
+        ok = ok && (r.off_mean + ROUND_NWAVES * 64 + F <= LDS);
     }
     return ok;
 }
@@ -881,7 +903,7 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         const int hid = max_hidden_pad(cl);
         int rb = 4;
         for (; rb > 1; rb >>= 1)
-            if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64 <= 40960) break;
+            if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64 + F <= 40960) break;
         s->p2_rb = rb;
         build_segments(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg);
         build_segments(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg);
@@ -945,6 +967,10 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             lrp = s->h_lrp_light.data();
         }
         build_tile_meta(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg, lrp, g->N, s->h_vmeta);
+        {   // 64-row records for P1's role B (graphs, first graph's rows / segments; no CSR ranges, no segment base)
+            std::vector<int32_t> none((size_t)(g->N + 63) / 64 + 1, 0), zero_rp(2 * (size_t)g->N + 1, 0);
+            build_tile_meta(g->h_var_seg, g->N, 64, none, s->h_vgseg, zero_rp.data(), -1, s->h_vmeta4);
+        }
         build_tile_meta(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg, g->h_c_rowptr.data(), -1,
                         s->h_cmeta);
     }
@@ -960,8 +986,8 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         const size_t meta_bytes = (s->h_vmeta.size() + s->h_vgseg.size() + s->h_cmeta.size() + s->h_cgseg.size() +
                                    s->h_lrp_light.size() + s->h_lcl_light.size() + s->h_lhv.size() +
                                    s->h_pieces.size() + s->h_vgseg2.size() + s->h_vchunks.size() +
-                                   s->h_cgseg2.size() + s->h_cchunks.size() + s->h_sel_tab.size()) * sizeof(int32_t) +
-                                  16 * 64;
+                                   s->h_cgseg2.size() + s->h_cchunks.size() + s->h_sel_tab.size() + s->h_vmeta4.size()) *
+                                      sizeof(int32_t) + 20 * 64;
         char* stage = static_cast<char*>(arena->take_pin(meta_bytes));
         if (s->slab == nullptr || stage == nullptr) return arena_full(arena, "dsat_session_create_in");
         e = hipMemsetAsync(s->slab, 0, s->slab_bytes, st);
@@ -996,6 +1022,7 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             if (e2 == hipSuccess) e2 = cp(s->cchunks, s->h_cchunks);
         }
         if (e2 == hipSuccess) e2 = cp(s->sel_tab, s->h_sel_tab);
+        if (e2 == hipSuccess) e2 = cp(s->vmeta4, s->h_vmeta4);
         if (e2 != hipSuccess) {
             (void)hipStreamDestroy(s->cap_stream);
             return hip_fail(e2, "segment upload", __FILE__, __LINE__);
@@ -1034,6 +1061,7 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             if (e2 == hipSuccess) e2 = cp(s->cchunks, s->h_cchunks);
         }
         if (e2 == hipSuccess) e2 = cp(s->sel_tab, s->h_sel_tab);
+        if (e2 == hipSuccess) e2 = cp(s->vmeta4, s->h_vmeta4);
         if (e2 != hipSuccess) {
             (void)hipFree(s->slab);
             return hip_fail(e2, "segment upload", __FILE__, __LINE__);
@@ -1366,12 +1394,20 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         // idle CUs of P1 finish the clause PairNorm of round r-1 (only worth it while the variable
         // tiles leave CUs idle; otherwise P2 does it in its prologue)
         const int vtiles = (s->g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
-        const int cn = (r > 0 && r < rounds && s->g->C > 0 && vtiles < 248 && !s->no_cn) ? 256 - vtiles : 0;
+        // role B (output / query pair on 64-row tiles) in every launch but the tail, which is the pair's
+        // output half alone
+        a1.pair_blocks = a1.tail ? 0 : s->pair_blocks;
+        const int free_cus = 256 - vtiles - a1.pair_blocks;
+        const int cn = (r > 0 && r < rounds && s->g->C > 0 && free_cus >= 8 && !s->no_cn) ? free_cus : 0;
         a1.cn_blocks = cn;
+        float* vbuf[2] = {s->V, s->Vlog};   // carried state, double-buffered by round (Vlog is free on this path)
+        a1.V_in = vbuf[(r & 1) ^ 1];
+        a1.V_out = vbuf[r & 1];
+        a1.V = a1.V_out;
         a1.psum_c_rd = s->psum_c + ((r + 1) & 1) * half;   // written by P2(r-1)
         L.run(KC_ROUND_P1, [&] { note(launch_round_p1(a1, st)); });   // also produces logits of round r-1
         if (tap != nullptr && r == tap->round) { tap_copy(tap->query, s->q, nf); tap_copy(tap->literals, s->lits, 2 * nf); }
-        if (tap != nullptr && r == tap->round + 1) tap_copy(tap->variables, s->V, nf);
+        if (tap != nullptr && r == tap->round + 1) tap_copy(tap->variables, a1.V_out, nf);
         if (r == rounds) {
             // R15-R17 of the last round (with early exit the earlier rounds' run inside P2)
             L.run(KC_SELECT_SAT, [&] {
@@ -1388,6 +1424,7 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
             a2.psum_c_rd = s->psum_c + ((r + 1) & 1) * half;
         }
         a3.round = r;
+        a3.V = a1.V_out;                    // the state P1 of this round wrote
         const bool tapped = tap != nullptr && r == tap->round;
         a2.tap_cmsg = tapped ? tap->clause_messages : nullptr;
         a3.tap_grad = tapped ? tap->variables_grad : nullptr;

@@ -190,6 +190,14 @@ struct RoundArgs {
     float *pgl, *out_logits;
     int32_t *best, *graph_unsat;
     uint8_t* assign;
+    // P1: the carried variable state is double-buffered by round: read V_in (previous round), write V_out;
+    // P3 and the taps read `V` (= this round's V_out)
+    const float* V_in;
+    float* V_out;
+    // P1 role B (kernels_round.hip): 64-row tiles running the output / query pair on otherwise idle CUs
+    const int32_t* vmeta4;   // per 64-row tile records
+    int pair_blocks;         // 0 = the 16-row tiles run the pair themselves
+    int b_off_x, b_off_vlog, b_off_a, b_off_b, b_off_mean, b_ld_a, b_ld_b;   // LDS plan of a role-B workgroup
     int s_enable;          // P2 only: append G blocks running select/SAT of round-1
     int cn_blocks;         // P1 only: extra blocks that finish the clause PairNorm of round-1 (R10)
                            //          on CUs the variable tiles leave idle; 0 = P2 does it itself
@@ -218,6 +226,7 @@ struct RoundArgs {
     float* tap_vloss;      // P3: variables_loss [2N,128] (pos rows, then neg)  (:269-273)
     // weights
     ChainSpec mq, mlit, mcl, mupd, mout;
+    ChainSpec mq4;         // variables_query blocked for 64-row tiles (role B, round 0)
     // LDS plan (float offsets / row strides), filled by plan_round_lds
     int ld_x, ld_a, ld_b, off_x, off_a, off_b, off_vlog, off_mean;
 };

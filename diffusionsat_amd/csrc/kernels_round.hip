@@ -117,8 +117,11 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
                                               const int32_t* __restrict__ seg, const int32_t* __restrict__ gseg,
                                               const float* __restrict__ psum, const int32_t* __restrict__ gseg2,
                                               const float* __restrict__ psum2, const float* __restrict__ x,
-                                              float* __restrict__ state, bool first, float* sState, int ldS,
+                                              const float* __restrict__ state_in, float* __restrict__ state_out,
+                                              bool first, float* sState, int ldS,
                                               float* sLogit, int ldL, float* sMean, int tid) {
+    // state_in: the carried state of the previous round; state_out: where this round's goes (nullptr:
+    // another workgroup normalises the same rows and owns the write).  sMean: (NT/F + 1) * F floats.
     constexpr int ROWS = (BM + NT / 32 - 1) / (NT / 32);
     const int tile_hi = min(tile_lo + BM, rows);
     const int sub = tid & 31, hw = tid >> 5;
@@ -131,7 +134,7 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
         const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
         for (int r = tile_lo + hw; r < tile_hi; r += NT / 32) {
             st4(sState + (r - tile_lo) * ldS + sub * 4, one);
-            st4(state + (size_t)r * F + sub * 4, one);
+            if (state_out != nullptr) st4(state_out + (size_t)r * F + sub * 4, one);
         }
         __syncthreads();
         return;
@@ -142,7 +145,7 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
         const int r = tile_lo + hw + k * (NT / 32);
         if (r < tile_hi) {
             xv[k] = ld4(x + (size_t)r * F + sub * 4);
-            ov[k] = ld4(state + (size_t)r * F + sub * 4);
+            ov[k] = ld4(state_in + (size_t)r * F + sub * 4);
         }
     }
     for (int g = tm.g_first; g <= tm.g_last; ++g) {
@@ -151,16 +154,25 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
         else { s0 = seg[g]; s1 = seg[g + 1]; gs0 = gseg[g]; gs1 = gseg[g + 1]; }
         const int lo = max(s0, tile_lo), hi = min(s1, tile_hi);
         if (lo >= hi) continue;   // wave-uniform
-        if (tid < F) {
-            // a graph spread over many tiles has had its segments pre-summed in chunks (segsum2_kernel)
+        {   // mean_g: the graph's per-tile column sums, NT/F of them requested at once (one memory round
+            // trip for the usual handful of segments), combined in a fixed order
+            constexpr int NG = NT / F;
             const float* ps = psum;
-            if (gseg2 != nullptr) {
+            if (gseg2 != nullptr) {   // many tiles: the segments were pre-summed in chunks (segsum2_kernel)
                 const int b0 = gseg2[g], b1 = gseg2[g + 1];
                 if (b1 > b0) { ps = psum2; gs0 = b0; gs1 = b1; }
             }
+            const int c = tid & (F - 1), grp = tid / F;
             float m = 0.f;
-            for (int sgi = gs0; sgi < gs1; ++sgi) m += ps[(size_t)sgi * F + tid];
-            sMean[tid] = m * (1.f / (float)(s1 - s0));
+            for (int sgi = gs0 + grp; sgi < gs1; sgi += NG) m += ps[(size_t)sgi * F + c];
+            sMean[F + tid] = m;
+            __syncthreads();
+            if (tid < F) {
+                float t = sMean[F + tid];
+#pragma unroll
+                for (int k = 1; k < NG; ++k) t += sMean[F + k * F + tid];
+                sMean[tid] = t * (1.f / (float)(s1 - s0));
+            }
         }
         __syncthreads();
         const float4 mean = ld4(sMean + sub * 4);
@@ -184,7 +196,7 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
                 res.z = __fadd_rn(__fmul_rn(res.z, 0.2f), __fmul_rn(res.z, 0.8f));
                 res.w = __fadd_rn(__fmul_rn(res.w, 0.2f), __fmul_rn(res.w, 0.8f));
                 st4(sState + (r - tile_lo) * ldS + sub * 4, res);
-                st4(state + (size_t)r * F + sub * 4, res);
+                if (state_out != nullptr) st4(state_out + (size_t)r * F + sub * 4, res);
             }
         }
         __syncthreads();
@@ -339,6 +351,27 @@ __device__ __forceinline__ void run_chain_pair(const ChainSpec& ma, const float*
     }
 }
 
+// The same pair on a 64-row tile (four row blocks per weight fragment): role B of P1, see below.
+template <typename StoreA, typename StoreB>
+__device__ __forceinline__ void run_chain_pair4(const ChainSpec& ma, const float* sInA, int ldinA, float* bufA, int ldA,
+                                                const ChainSpec& mb, const float* sInB, int ldinB, float* bufB, int ldB,
+                                                int wave, int lane, StoreA&& storeA, StoreB&& storeB) {
+    static_assert(ROUND_NWAVES == 16, "the 64-row pair is built for 16 waves (host: pair_blocks = 0 otherwise)");
+    constexpr int H = ROUND_NWAVES / 2;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const StaticLayer none{nullptr, nullptr, 0, 0};
+    if (wv < H) {
+        const StaticLayer S0{ma.L[0].wp, ma.L[0].bias, ma.L[0].kblocks, ma.L[0].ntiles};
+        const StaticLayer S1{ma.L[1].wp, ma.L[1].bias, ma.L[1].kblocks, ma.L[1].ntiles};
+        chain_static<4, H, 1, 1, 0>(S0, S1, none, sInA, ldinA, bufA, ldA, nullptr, 0, wv, lane, storeA, false);
+    } else {
+        const StaticLayer S0{mb.L[0].wp, mb.L[0].bias, mb.L[0].kblocks, mb.L[0].ntiles};
+        const StaticLayer S1{mb.L[1].wp, mb.L[1].bias, mb.L[1].kblocks, mb.L[1].ntiles};
+        chain_static<4, H, 2, 1, 0>(S0, S1, none, sInB, ldinB, bufB, ldB, nullptr, 0, wv - H, lane, storeB, false);
+    }
+    __syncthreads();
+}
+
 // CSR entries of the tile's rows -> LDS (entry ranges of consecutive rows are contiguous):
 // sPtr[i] = rowptr[row_lo + i] - e_base for i = 0..nrows, sIdx[k] = idx[e_base + k].
 // Returns false (nothing staged) when the range does not fit `cap` entries.
@@ -373,16 +406,25 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
         const int s0 = a.cl_seg[g], s1 = a.cl_seg[g + 1];
         const int lo = max(s0, lo0), hi = min(s1, hi0);
         if (lo >= hi) continue;
-        if (tid < F) {
+        {
+            constexpr int NG = NT / F;
             const float* ps = a.psum_c_rd;
             int gs0 = a.cgseg[g], gs1 = a.cgseg[g + 1];
             if (a.cgseg2 != nullptr) {
                 const int b0 = a.cgseg2[g], b1 = a.cgseg2[g + 1];
                 if (b1 > b0) { ps = a.psum2_c; gs0 = b0; gs1 = b1; }
             }
+            const int c = tid & (F - 1), grp = tid / F;
             float m = 0.f;
-            for (int sgi = gs0; sgi < gs1; ++sgi) m += ps[(size_t)sgi * F + tid];
-            sMean[tid] = m * (1.f / (float)(s1 - s0));
+            for (int sgi = gs0 + grp; sgi < gs1; sgi += NG) m += ps[(size_t)sgi * F + c];
+            sMean[F + tid] = m;
+            __syncthreads();
+            if (tid < F) {
+                float t = sMean[F + tid];
+#pragma unroll
+                for (int k = 1; k < NG; ++k) t += sMean[F + k * F + tid];
+                sMean[tid] = t * (1.f / (float)(s1 - s0));
+            }
         }
         __syncthreads();
         const float4 mean = ld4(sMean + sub * 4);
@@ -408,22 +450,81 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
 }
 
 // ------------------------------------------------------------------------------------- P1
-// Blocks [0, vtiles) are variable tiles; blocks [vtiles, vtiles + cn_blocks) finish the clause
-// PairNorm of the previous round (it depends on P2(r-1) only), off P2's critical path.
+// Three roles in one grid:
+//   A  blocks [0, vtiles): 16-row variable tiles -- PairNorm (R13, writes the carried state), lit_mlp (R6);
+//      without role B also the output / query pair (R14, R2).
+//   B  blocks [vtiles, vtiles + pair_blocks): 64-row tiles -- the same PairNorm again (registers and LDS
+//      only; role A owns the state write), then variables_output and variables_query side by side with
+//      four row blocks per weight fragment.  At 20k nodes the 194 A tiles leave 62 CUs idle and a
+//      kernel lasts one tile: moving the pair (a fifth of a tile's time, and a poor fit for 16-row
+//      tiles: two small layers each) to those CUs shortens every A tile, and the 64-row form does the
+//      pair's MFMA work with a quarter of the weight traffic and fixed per-layer cost per row.
+//   C  blocks after that: finish the clause PairNorm of the previous round (R10; depends on P2(r-1)
+//      only), off P2's critical path.
+// The carried state is double-buffered by round (V_in -> V_out): A and B both read the old state.
 __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     constexpr int BM = ROUND_BM_VAR;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.N;
     const int vtiles = (N + BM - 1) / BM;
-    const bool extra = (int)blockIdx.x >= vtiles;
-    const int tile = extra ? 0 : xcd_tile(blockIdx.x, vtiles);
+    const int b = blockIdx.x;
+    const bool roleA = b < vtiles, roleB = !roleA && b < vtiles + a.pair_blocks;
+    const int tile = roleA ? xcd_tile(b, vtiles) : (roleB ? b - vtiles : 0);
     // the early-exit flag and the tile record are requested together: one memory latency, not two
     const int done = a.check_done ? a.ctl->done : 0;
-    const TileMetaDev tm = load_meta(a.vmeta, tile);
+    const TileMetaDev tm = load_meta(roleB ? a.vmeta4 : a.vmeta, tile);
     if (both_arrived(done, tm) != 0) return;
-    if (extra) {
-        clause_norm_block(a, blockIdx.x - vtiles, a.cn_blocks, smem, tid);
+    if (!roleA && !roleB) {
+        clause_norm_block(a, b - vtiles - a.pair_blocks, a.cn_blocks, smem, tid);
+        return;
+    }
+    const int ldx = a.ld_x, ldv = F + 8;
+    float* lg = a.logits;
+    float* tr = a.trace_logits != nullptr && a.round > 0
+                    ? a.trace_logits + (size_t)(a.round - 1) * N * LOGIT_MAPS : nullptr;
+    float* q = a.q;
+    float* sp = a.sp;
+    if (roleB) {
+        constexpr int BM4 = 64;
+        const int tile_lo = tile * BM4;
+        float* sX = smem + a.b_off_x;
+        float* sVlog = smem + a.b_off_vlog;
+        float* sA = smem + a.b_off_a;
+        float* sB = smem + a.b_off_b;
+        float* sMean = smem + a.b_off_mean;
+        if (tid < BM4) {
+            const int n = tile_lo + tid;
+            load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N);
+        }
+        pairnorm_tile<BM4>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, nullptr,
+                           a.round == 0, sX, ldx, sVlog, ldv, sMean, tid);
+        auto store_logits = [=](int row, int col, float4 v) {
+            const int n = tile_lo + row;
+            if (n < N && col < LOGIT_MAPS) {
+                st4(lg + (size_t)n * LOGIT_MAPS + col, v);
+                if (tr != nullptr) st4(tr + (size_t)n * LOGIT_MAPS + col, v);
+            }
+        };
+        auto store_query = [=](int row, int col, float4 v) {
+            const int n = tile_lo + row;
+            if (n < N && col < F) {
+                st4(q + (size_t)n * F + col, v);
+                const float4 t = make_float4(log1pf(expf(-fabsf(v.x))), log1pf(expf(-fabsf(v.y))),
+                                             log1pf(expf(-fabsf(v.z))), log1pf(expf(-fabsf(v.w))));
+                st4(sp + (size_t)n * F + col, make_float4(fmaxf(v.x, 0.f) + t.x, fmaxf(v.y, 0.f) + t.y,
+                                                          fmaxf(v.z, 0.f) + t.z, fmaxf(v.w, 0.f) + t.w));
+                st4(sp + (size_t)(N + n) * F + col, make_float4(fmaxf(-v.x, 0.f) + t.x, fmaxf(-v.y, 0.f) + t.y,
+                                                                fmaxf(-v.z, 0.f) + t.z, fmaxf(-v.w, 0.f) + t.w));
+            }
+        };
+        if constexpr (ROUND_NWAVES == 16) {
+            if (a.round > 0)
+                run_chain_pair4(a.mout, sVlog, ldv, sA, a.b_ld_a, a.mq, sX, ldx, sB, a.b_ld_b, wave, lane, store_logits,
+                                store_query);
+            else   // round 0 has no previous logits: the query alone, all waves
+                run_chain<4>(a.mq4, sX, ldx, sB, a.b_ld_b, sA, a.b_ld_a, wave, lane, store_query);
+        }
         return;
     }
     const int tile_lo = tile * BM;
@@ -432,7 +533,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     float* sA = smem + a.off_a;
     float* sB = smem + a.off_b;
     float* sMean = smem + a.off_mean;
-    const int ldx = a.ld_x, ldv = F + 8;
+    const bool pair_here = a.pair_blocks == 0;   // no role B in this launch: the tile runs the pair itself
 
     DSAT_STAMP_RT_BEGIN(a);
     DSAT_STAMP(a, 0);
@@ -440,46 +541,45 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
         const int n = tile_lo + tid;
         load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N && !a.tail);
     }
-    pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V, a.round == 0, sX, ldx, sVlog,
-                      ldv, sMean, tid);
+    pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, a.V_out,
+                      a.round == 0, sX, ldx, pair_here ? sVlog : nullptr, ldv, sMean, tid);
     DSAT_STAMP(a, 1);
 
-    float* lg = a.logits;
-    float* tr = a.trace_logits != nullptr && a.round > 0
-                    ? a.trace_logits + (size_t)(a.round - 1) * N * LOGIT_MAPS : nullptr;
-    float* q = a.q;
-    float* sp = a.sp;
-    // R14: logits of the previous round from the pre-mix state
-    auto store_logits = [=](int row, int col, float4 v) {
-        const int n = tile_lo + row;
-        if (n < N && col < LOGIT_MAPS) {
-            st4(lg + (size_t)n * LOGIT_MAPS + col, v);
-            if (tr != nullptr) st4(tr + (size_t)n * LOGIT_MAPS + col, v);
+    if (pair_here) {
+        // R14: logits of the previous round from the pre-mix state
+        auto store_logits = [=](int row, int col, float4 v) {
+            const int n = tile_lo + row;
+            if (n < N && col < LOGIT_MAPS) {
+                st4(lg + (size_t)n * LOGIT_MAPS + col, v);
+                if (tr != nullptr) st4(tr + (size_t)n * LOGIT_MAPS + col, v);
+            }
+        };
+        // R2: query = variables_query(v1); softplus(+-query) feeds the clause gather (loss/sat.py:132-133)
+        auto store_query = [=](int row, int col, float4 v) {
+            const int n = tile_lo + row;
+            if (n < N && col < F) {
+                st4(q + (size_t)n * F + col, v);
+                // softplus(+-x) = max(+-x, 0) + log1p(exp(-|x|)): one transcendental pair serves both signs
+                const float4 t = make_float4(log1pf(expf(-fabsf(v.x))), log1pf(expf(-fabsf(v.y))),
+                                             log1pf(expf(-fabsf(v.z))), log1pf(expf(-fabsf(v.w))));
+                st4(sp + (size_t)n * F + col, make_float4(fmaxf(v.x, 0.f) + t.x, fmaxf(v.y, 0.f) + t.y,
+                                                          fmaxf(v.z, 0.f) + t.z, fmaxf(v.w, 0.f) + t.w));
+                st4(sp + (size_t)(N + n) * F + col, make_float4(fmaxf(-v.x, 0.f) + t.x, fmaxf(-v.y, 0.f) + t.y,
+                                                                fmaxf(-v.z, 0.f) + t.z, fmaxf(-v.w, 0.f) + t.w));
+            }
+        };
+        if (a.round > 0 && !a.tail && a.mout.nlayers == 2 && a.mq.nlayers == 2) {
+            run_chain_pair(a.mout, sVlog, ldv, sA, a.ld_a, a.mq, sX, ldx, sB, a.ld_b, wave, lane, store_logits,
+                           store_query);
+            DSAT_STAMP(a, 2);
+        } else {
+            if (a.round > 0) run_chain<1>(a.mout, sVlog, ldv, sA, a.ld_a, sB, a.ld_b, wave, lane, store_logits);
+            DSAT_STAMP(a, 2);
+            if (a.tail) return;
+            run_chain<1>(a.mq, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, store_query);
         }
-    };
-    // R2: query = variables_query(v1); softplus(+-query) feeds the clause gather (loss/sat.py:132-133)
-    auto store_query = [=](int row, int col, float4 v) {
-        const int n = tile_lo + row;
-        if (n < N && col < F) {
-            st4(q + (size_t)n * F + col, v);
-            // softplus(+-x) = max(+-x, 0) + log1p(exp(-|x|)): one transcendental pair serves both signs
-            const float4 t = make_float4(log1pf(expf(-fabsf(v.x))), log1pf(expf(-fabsf(v.y))),
-                                         log1pf(expf(-fabsf(v.z))), log1pf(expf(-fabsf(v.w))));
-            st4(sp + (size_t)n * F + col, make_float4(fmaxf(v.x, 0.f) + t.x, fmaxf(v.y, 0.f) + t.y,
-                                                      fmaxf(v.z, 0.f) + t.z, fmaxf(v.w, 0.f) + t.w));
-            st4(sp + (size_t)(N + n) * F + col, make_float4(fmaxf(-v.x, 0.f) + t.x, fmaxf(-v.y, 0.f) + t.y,
-                                                            fmaxf(-v.z, 0.f) + t.z, fmaxf(-v.w, 0.f) + t.w));
-        }
-    };
-    if (a.round > 0 && !a.tail && a.mout.nlayers == 2 && a.mq.nlayers == 2) {
-        run_chain_pair(a.mout, sVlog, ldv, sA, a.ld_a, a.mq, sX, ldx, sB, a.ld_b, wave, lane, store_logits,
-                       store_query);
-        DSAT_STAMP(a, 2);
     } else {
-        if (a.round > 0) run_chain<1>(a.mout, sVlog, ldv, sA, a.ld_a, sB, a.ld_b, wave, lane, store_logits);
         DSAT_STAMP(a, 2);
-        if (a.tail) return;
-        run_chain<1>(a.mq, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, store_query);
     }
     DSAT_STAMP(a, 3);
     {   // R6: literals = [lit_mlp(v1)[:, :128] ; [:, 128:]]
@@ -542,7 +642,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
         }
         __syncthreads();
     } else {
-        pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.cgseg2, a.psum2_c, a.ncv, a.Cs, a.round == 0, sX, ldx,
+        pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.cgseg2, a.psum2_c, a.ncv, a.Cs, a.Cs, a.round == 0, sX, ldx,
                           nullptr, 0, sMean, tid);   // its barriers also publish sPtr / sIdx
     }
     DSAT_STAMP(a, 1);
@@ -1054,7 +1154,7 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
 }  // namespace
 
 hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st) {
-    const int tiles = (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + a.cn_blocks;
+    const int tiles = (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + a.pair_blocks + a.cn_blocks;
     hipLaunchKernelGGL(round_p1_kernel, dim3(tiles), dim3(NT), 0, st, a);
     return hipGetLastError();
 }
