@@ -822,6 +822,7 @@ static bool plan_round(dsat_session* s) {
         ok = ok && (r.off_mean + mean_floats <= LDS);
         // role B: 64-row tiles for the output / query pair (kernels_round.hip, round_p1_kernel)
         r.mq4 = make_chain(w->mlp[DSAT_MLP_VARIABLES_QUERY], 4);
+        r.mout4 = make_chain(w->mlp[DSAT_MLP_VARIABLES_OUTPUT], 4);
         r.vmeta4 = s->vmeta4;
         r.b_ld_a = max_hidden_pad(w->mlp[DSAT_MLP_VARIABLES_OUTPUT]) + 8;
         r.b_ld_b = max_hidden_pad(w->mlp[DSAT_MLP_VARIABLES_QUERY]) + 8;
@@ -831,9 +832,7 @@ static bool plan_round(dsat_session* s) {
         r.b_off_b = r.b_off_a + 64 * r.b_ld_a;
         r.b_off_mean = r.b_off_b + 64 * r.b_ld_b;
         const bool fits = r.b_off_mean + mean_floats <= LDS;
-        const bool shapes = ROUND_NWAVES == 16 && r.mout.nlayers == 2 && r.mq.nlayers == 2 &&
-                            r.mout.static_half_id == CHAIN_H11 && r.mq.static_half_id == CHAIN_H21 &&
-                            r.mq4.static_id == CHAIN_11;
+        const bool shapes = ROUND_NWAVES == 16 && r.mq4.static_id == CHAIN_11 && r.mout4.static_id == CHAIN_11;
         s->pair_blocks = (fits && shapes && getenv("DSAT_NO_PAIRB") == nullptr) ? (g->N + 63) / 64 : 0;
     }
     {   // P2: [X BMx392 | A | (B) | mean]

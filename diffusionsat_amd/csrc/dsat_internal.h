@@ -226,7 +226,7 @@ struct RoundArgs {
     float* tap_vloss;      // P3: variables_loss [2N,128] (pos rows, then neg)  (:269-273)
     // weights
     ChainSpec mq, mlit, mcl, mupd, mout;
-    ChainSpec mq4;         // variables_query blocked for 64-row tiles (role B, round 0)
+    ChainSpec mq4, mout4;  // variables_query / variables_output blocked for 64-row tiles (P1 role B)
     // LDS plan (float offsets / row strides), filled by plan_round_lds
     int ld_x, ld_a, ld_b, off_x, off_a, off_b, off_vlog, off_mean;
 };

@@ -41,6 +41,11 @@ constexpr int NT = ROUND_NWAVES * 64;
         if ((a).stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096)                 \
             (a).stamps[blockIdx.x * 8 + 7] = (long long)(__builtin_amdgcn_s_memrealtime() - _rt0); \
     } while (0)
+// Epilogue addresses are per-lane 64-bit values; computed from loop-invariant inputs, the compiler
+// hoists them above the whole MLP chain, where they sit in VGPR pairs for tens of thousands of cycles
+// and push a 1024-thread workgroup (128 VGPRs per lane) into scratch spills.  An empty asm on the row
+// index pins the address arithmetic to the epilogue.
+#define NO_HOIST(x) asm volatile("" : "+v"(x))
 constexpr int LDS_FLOATS = 40960;   // 160 KiB static (see kernels_chain.hip on dynamic LDS)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -351,27 +356,6 @@ __device__ __forceinline__ void run_chain_pair(const ChainSpec& ma, const float*
     }
 }
 
-// The same pair on a 64-row tile (four row blocks per weight fragment): role B of P1, see below.
-template <typename StoreA, typename StoreB>
-__device__ __forceinline__ void run_chain_pair4(const ChainSpec& ma, const float* sInA, int ldinA, float* bufA, int ldA,
-                                                const ChainSpec& mb, const float* sInB, int ldinB, float* bufB, int ldB,
-                                                int wave, int lane, StoreA&& storeA, StoreB&& storeB) {
-    static_assert(ROUND_NWAVES == 16, "the 64-row pair is built for 16 waves (host: pair_blocks = 0 otherwise)");
-    constexpr int H = ROUND_NWAVES / 2;
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const StaticLayer none{nullptr, nullptr, 0, 0};
-    if (wv < H) {
-        const StaticLayer S0{ma.L[0].wp, ma.L[0].bias, ma.L[0].kblocks, ma.L[0].ntiles};
-        const StaticLayer S1{ma.L[1].wp, ma.L[1].bias, ma.L[1].kblocks, ma.L[1].ntiles};
-        chain_static<4, H, 1, 1, 0>(S0, S1, none, sInA, ldinA, bufA, ldA, nullptr, 0, wv, lane, storeA, false);
-    } else {
-        const StaticLayer S0{mb.L[0].wp, mb.L[0].bias, mb.L[0].kblocks, mb.L[0].ntiles};
-        const StaticLayer S1{mb.L[1].wp, mb.L[1].bias, mb.L[1].kblocks, mb.L[1].ntiles};
-        chain_static<4, H, 2, 1, 0>(S0, S1, none, sInB, ldinB, bufB, ldB, nullptr, 0, wv - H, lane, storeB, false);
-    }
-    __syncthreads();
-}
-
 // CSR entries of the tile's rows -> LDS (entry ranges of consecutive rows are contiguous):
 // sPtr[i] = rowptr[row_lo + i] - e_base for i = 0..nrows, sIdx[k] = idx[e_base + k].
 // Returns false (nothing staged) when the range does not fit `cap` entries.
@@ -386,7 +370,7 @@ __device__ __forceinline__ bool stage_csr(const int32_t* __restrict__ rowptr, co
 
 // R15-R17 for one graph (forward declaration; defined with the stand-alone kernel below)
 template <int NTH>
-__device__ void select_sat_body(int blk, int nblocks, const int32_t* __restrict__ sel_tab,
+__device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int32_t* __restrict__ sel_tab,
                                 const int32_t* __restrict__ vseg,
                                 const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
                                 const int32_t* __restrict__ c_lit, const float* __restrict__ logits,
@@ -454,8 +438,8 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
 //   A  blocks [0, vtiles): 16-row variable tiles -- PairNorm (R13, writes the carried state), lit_mlp (R6);
 //      without role B also the output / query pair (R14, R2).
 //   B  blocks [vtiles, vtiles + pair_blocks): 64-row tiles -- the same PairNorm again (registers and LDS
-//      only; role A owns the state write), then variables_output and variables_query side by side with
-//      four row blocks per weight fragment.  At 20k nodes the 194 A tiles leave 62 CUs idle and a
+//      only; role A owns the state write), then variables_output and variables_query with four row
+//      blocks per weight fragment.  At 20k nodes the 194 A tiles leave 62 CUs idle and a
 //      kernel lasts one tile: moving the pair (a fifth of a tile's time, and a poor fit for 16-row
 //      tiles: two small layers each) to those CUs shortens every A tile, and the 64-row form does the
 //      pair's MFMA work with a quarter of the weight traffic and fixed per-layer cost per row.
@@ -500,14 +484,16 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
         pairnorm_tile<BM4>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, nullptr,
                            a.round == 0, sX, ldx, sVlog, ldv, sMean, tid);
         auto store_logits = [=](int row, int col, float4 v) {
-            const int n = tile_lo + row;
+            int n = tile_lo + row;
+            NO_HOIST(n);
             if (n < N && col < LOGIT_MAPS) {
                 st4(lg + (size_t)n * LOGIT_MAPS + col, v);
                 if (tr != nullptr) st4(tr + (size_t)n * LOGIT_MAPS + col, v);
             }
         };
         auto store_query = [=](int row, int col, float4 v) {
-            const int n = tile_lo + row;
+            int n = tile_lo + row;
+            NO_HOIST(n);
             if (n < N && col < F) {
                 st4(q + (size_t)n * F + col, v);
                 const float4 t = make_float4(log1pf(expf(-fabsf(v.x))), log1pf(expf(-fabsf(v.y))),
@@ -518,13 +504,11 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
                                                                 fmaxf(-v.z, 0.f) + t.z, fmaxf(-v.w, 0.f) + t.w));
             }
         };
-        if constexpr (ROUND_NWAVES == 16) {
-            if (a.round > 0)
-                run_chain_pair4(a.mout, sVlog, ldv, sA, a.b_ld_a, a.mq, sX, ldx, sB, a.b_ld_b, wave, lane, store_logits,
-                                store_query);
-            else   // round 0 has no previous logits: the query alone, all waves
-                run_chain<4>(a.mq4, sX, ldx, sB, a.b_ld_b, sA, a.b_ld_a, wave, lane, store_query);
-        }
+        // the two small chains one after the other, each on all waves with four row blocks per weight
+        // fragment (side by side on half the waves each, as the 16-row pair runs them, the query half
+        // needs two column tiles per wave: more registers than a 1024-thread workgroup has)
+        if (a.round > 0) run_chain<4>(a.mout4, sVlog, ldv, sA, a.b_ld_a, sB, a.b_ld_b, wave, lane, store_logits);
+        run_chain<4>(a.mq4, sX, ldx, sB, a.b_ld_b, sA, a.b_ld_a, wave, lane, store_query);
         return;
     }
     const int tile_lo = tile * BM;
@@ -548,7 +532,8 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     if (pair_here) {
         // R14: logits of the previous round from the pre-mix state
         auto store_logits = [=](int row, int col, float4 v) {
-            const int n = tile_lo + row;
+            int n = tile_lo + row;
+            NO_HOIST(n);
             if (n < N && col < LOGIT_MAPS) {
                 st4(lg + (size_t)n * LOGIT_MAPS + col, v);
                 if (tr != nullptr) st4(tr + (size_t)n * LOGIT_MAPS + col, v);
@@ -556,7 +541,8 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
         };
         // R2: query = variables_query(v1); softplus(+-query) feeds the clause gather (loss/sat.py:132-133)
         auto store_query = [=](int row, int col, float4 v) {
-            const int n = tile_lo + row;
+            int n = tile_lo + row;
+            NO_HOIST(n);
             if (n < N && col < F) {
                 st4(q + (size_t)n * F + col, v);
                 // softplus(+-x) = max(+-x, 0) + log1p(exp(-|x|)): one transcendental pair serves both signs
@@ -585,7 +571,8 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     {   // R6: literals = [lit_mlp(v1)[:, :128] ; [:, 128:]]
         float* lits = a.lits;
         run_chain<1>(a.mlit, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float4 v) {
-            const int n = tile_lo + row;
+            int n = tile_lo + row;
+            NO_HOIST(n);
             if (n < N && col < 2 * F) st4(lits + ((size_t)(col < F ? n : N + n)) * F + (col & (F - 1)), v);
         });
     }
@@ -730,7 +717,8 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
         float* stage = sX;   // the input tile is dead once layer 0 has run
         const int lds = F + 8;
         run_chain<RB>(a.mcl, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float4 v) {
-            const int c = tile_lo + row;
+            int c = tile_lo + row;
+            NO_HOIST(c);
             if (col < F) {
                 if (c < C) st4(vla + (size_t)c * F + col, v);
             } else if (col < 2 * F) {
@@ -919,7 +907,8 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
         float* stage = sX;
         const int lds = F + 8;
         run_chain<1>(a.mupd, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float4 v) {
-            const int n = tile_lo + row;
+            int n = tile_lo + row;
+            NO_HOIST(n);
             if (col < F) {
                 st4(stage + row * lds + col, v);
                 if (n < N) st4(newv + (size_t)n * F + col, v);
@@ -1022,7 +1011,7 @@ __device__ __forceinline__ float bern_kl(float a, float b) {
 // straight from the logits, so no part waits for another's bits.  Unsatisfied-clause counts meet in
 // graph_unsat (integer atomics; zeroed by P3 before every select when parts > 1).
 template <int NTH>
-__device__ void select_sat_body(int blk, int nblocks, const int32_t* __restrict__ sel_tab,
+__device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int32_t* __restrict__ sel_tab,
                                 const int32_t* __restrict__ vseg,
                                 const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
                                 const int32_t* __restrict__ c_lit, const float* __restrict__ logits,
