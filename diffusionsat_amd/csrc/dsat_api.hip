@@ -842,7 +842,7 @@ static bool plan_round(dsat_session* s) {
         int rb = 4;
         for (; rb >= 1; rb >>= 1) {
             const int bm = 16 * rb;
-            const int need = bm * (3 * F + 8) + bm * (hid + 8) * (layers.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64 + F;
+            const int need = bm * (3 * F + 8) + bm * (hid + 8) * (layers.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64;
             if (need <= LDS) break;
         }
         ok = ok && rb >= 1;
@@ -857,7 +857,7 @@ static bool plan_round(dsat_session* s) {
         r.off_a = bm * r.ld_x;
         r.off_b = layers.size() > 2 ? r.off_a + bm * r.ld_a : r.off_a;
         r.off_mean = r.off_b + bm * r.ld_b;
-        ok = ok && (r.off_mean + (ROUND_NWAVES * 64 / F + 1) * F <= LDS);
+        ok = ok && (r.off_mean + ROUND_NWAVES * 64 <= LDS);
     }
     {   // P3: [X 16x536 | A | B]
         RoundArgs& r = s->ra3;
@@ -877,7 +877,7 @@ static bool plan_round(dsat_session* s) {
         r.off_a = ROUND_BM_VAR * r.ld_x;
         r.off_b = r.off_a + ROUND_BM_VAR * r.ld_a;
         r.off_mean = r.off_b + ROUND_BM_VAR * r.ld_b;
-        ok = ok && (r.off_mean + ROUND_NWAVES * 64 + F <= LDS);
+        ok = ok && (r.off_mean + ROUND_NWAVES * 64 <= LDS);
     }
     return ok;
 }
@@ -902,7 +902,7 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         const int hid = max_hidden_pad(cl);
         int rb = 4;
         for (; rb > 1; rb >>= 1)
-            if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64 + F <= 40960) break;
+            if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64 <= 40960) break;
         s->p2_rb = rb;
         build_segments(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg);
         build_segments(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg);

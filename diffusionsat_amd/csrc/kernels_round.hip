@@ -124,9 +124,10 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
                                               const float* __restrict__ psum2, const float* __restrict__ x,
                                               const float* __restrict__ state_in, float* __restrict__ state_out,
                                               bool first, float* sState, int ldS,
-                                              float* sLogit, int ldL, float* sMean, int tid) {
+                                              float* sLogit, int ldL, float* sMean, float* sPart, int ldP, int tid) {
     // state_in: the carried state of the previous round; state_out: where this round's goes (nullptr:
-    // another workgroup normalises the same rows and owns the write).  sMean: (NT/F + 1) * F floats.
+    // another workgroup normalises the same rows and owns the write).  sMean: F floats; sPart: NT/F rows
+    // of F floats, row stride ldP (scratch for the partial sums of the thread groups).
     constexpr int ROWS = (BM + NT / 32 - 1) / (NT / 32);
     const int tile_hi = min(tile_lo + BM, rows);
     const int sub = tid & 31, hw = tid >> 5;
@@ -170,12 +171,12 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
             const int c = tid & (F - 1), grp = tid / F;
             float m = 0.f;
             for (int sgi = gs0 + grp; sgi < gs1; sgi += NG) m += ps[(size_t)sgi * F + c];
-            sMean[F + tid] = m;
+            sPart[grp * ldP + c] = m;
             __syncthreads();
             if (tid < F) {
-                float t = sMean[F + tid];
+                float t = sPart[tid];
 #pragma unroll
-                for (int k = 1; k < NG; ++k) t += sMean[F + k * F + tid];
+                for (int k = 1; k < NG; ++k) t += sPart[k * ldP + tid];
                 sMean[tid] = t * (1.f / (float)(s1 - s0));
             }
         }
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
             load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N);
         }
         pairnorm_tile<BM4>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, nullptr,
-                           a.round == 0, sX, ldx, sVlog, ldv, sMean, tid);
+                           a.round == 0, sX, ldx, sVlog, ldv, sMean, sMean + F, F, tid);
         auto store_logits = [=](int row, int col, float4 v) {
             int n = tile_lo + row;
             NO_HOIST(n);
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
         load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N && !a.tail);
     }
     pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, a.V_out,
-                      a.round == 0, sX, ldx, pair_here ? sVlog : nullptr, ldv, sMean, tid);
+                      a.round == 0, sX, ldx, pair_here ? sVlog : nullptr, ldv, sMean, sMean + F, F, tid);
     DSAT_STAMP(a, 1);
 
     if (pair_here) {
@@ -630,7 +631,8 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
         __syncthreads();
     } else {
         pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.cgseg2, a.psum2_c, a.ncv, a.Cs, a.Cs, a.round == 0, sX, ldx,
-                          nullptr, 0, sMean, tid);   // its barriers also publish sPtr / sIdx
+                          nullptr, 0, sMean, sX + F, ldx, tid);   // its barriers also publish sPtr / sIdx
+        // (the partial sums borrow columns 128.. of the tile's first rows, which the gather fills later)
     }
     DSAT_STAMP(a, 1);
     // R3 + R5 + R7: half-wave hw owns rows hw, hw+16, ...; all its rows (ROWS <= 4) are in
