@@ -58,9 +58,14 @@ def collect(config, rounds):
     st = np.frombuffer(buf, dtype=np.int64).reshape(3, 4096, 8).copy()
     tiles = [min(4096, (batch.n_vars + 15) // 16), min(4096, (batch.n_clauses + 63) // 64),
              min(4096, (batch.n_vars + 15) // 16)]
-    return {"round_p1": st[0, :tiles[0]], "round_p2": st[1, :tiles[1]], "round_p3": st[2, :tiles[2]]}, \
-        {"config": config, "rounds": rounds, "n_vars": batch.n_vars, "n_clauses": batch.n_clauses,
-         "n_graphs": batch.n_graphs}
+    out = {"round_p1": st[0, :tiles[0]], "round_p2": st[1, :tiles[1]], "round_p3": st[2, :tiles[2]]}
+    # the other workgroups of the same grids (role B / clause-norm blocks of P1, select/SAT blocks of P2):
+    # whatever follows the tiles and carries stamps
+    for name, k in (("round_p1_extra", 0), ("round_p2_extra", 1)):
+        rest = st[k, tiles[k]:]
+        out[name] = rest[rest[:, 7] > 0]
+    return out, {"config": config, "rounds": rounds, "n_vars": batch.n_vars, "n_clauses": batch.n_clauses,
+                 "n_graphs": batch.n_graphs}
 
 
 def table(stamps, meta):
@@ -86,6 +91,24 @@ def table(stamps, meta):
             lines.append("    %-34s median %8.0f  max %8.0f cycles  (%4.1f %%)" % (
                 name, np.median(d), d.max(), 100 * np.median(d) / np.median(tot)))
         out["kernels"][k] = kk
+    for k, what in (("round_p1_extra", "P1 role B (64-row pair: pairnorm | out chain | query chain) and role C "
+                                       "(clause-norm) workgroups"),
+                    ("round_p2_extra", "P2 select/SAT workgroups")):
+        if k in stamps and len(stamps[k]):
+            t = stamps[k].astype(np.float64)
+            tot = t[:, 4] - t[:, 0]
+            isb = t[:, 2] > 0            # role B stamps its chain boundaries, role C / select do not
+            lines.append("%s: %d workgroups" % (what, len(tot)))
+            for nm, m in (("with chain stamps", isb), ("without", ~isb)):
+                if m.any():
+                    lines.append("    %-18s n=%3d  median %8.0f  max %8.0f cycles" % (nm, m.sum(), np.median(tot[m]),
+                                                                                      tot[m].max()))
+                    out["kernels"][k + ("_b" if nm.startswith("with ") else "_c")] = {
+                        "n": int(m.sum()), "cycles_median": float(np.median(tot[m])), "cycles_max": float(tot[m].max())}
+            if isb.any():
+                for nm, lo, hi in (("pairnorm(64 rows)", 0, 1), ("out chain", 1, 2), ("query chain", 2, 3)):
+                    d = t[isb][:, hi] - t[isb][:, lo]
+                    lines.append("      %-18s median %8.0f  max %8.0f" % (nm, np.median(d), d.max()))
     return out, "\n".join(lines)
 
 
@@ -98,7 +121,7 @@ def main():
     a = ap.parse_args()
     if a.src:
         z = np.load(a.src, allow_pickle=False)
-        stamps = {k: z[k] for k in ("round_p1", "round_p2", "round_p3")}
+        stamps = {k: z[k] for k in z.files if k != "meta"}
         meta = json.loads(str(z["meta"]))
     else:
         stamps, meta = collect(a.config, a.rounds)
