@@ -64,9 +64,11 @@ __device__ __forceinline__ void stg4(float* p, float4 v) {
 #else
     f32x4 x = {v.x, v.y, v.z, v.w};
 #if DSAT_OUT_POLICY == 1
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+    // s_nop: a store wider than 64 bits still reads its data VGPRs in the cycle after issue; the
+    // compiler pads that hazard for its own stores but cannot see inside an asm statement
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 #else
-    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(x) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 #endif
 #endif
 }
