@@ -119,9 +119,10 @@ class QuerySAT:
             self.set_weights(load_npz(path))
             return True
         from . import tf_checkpoint
-        ws = tf_checkpoint.load_queriesat_weights(path, self.layout)
+        ws = tf_checkpoint.load_queriesat_weights(path, self.layout, base=self._weights_host)   # expect_partial()
         if ws is None:
             return False
+        self.restore_report = dict(tf_checkpoint.last_restore_report)
         self.set_weights(ws)
         return True
 

@@ -14,11 +14,15 @@ the attribute names of model/query_sat.py:117-122 and model/mlp.py:24,37-39):
 
   ``model/<mlp>/dense_layers/<i>/{kernel,bias}/.ATTRIBUTES/VARIABLE_VALUE``
 
-UNVERIFIED AGAINST A TENSORFLOW-WRITTEN FILE: no checkpoint ships with the reference
-(README.md:38-40 points to GitHub Releases) and TensorFlow is not installed here, so the
-format knowledge is from the published TensorBundle / leveldb table layouts; the tests
-round-trip files written by ``write_checkpoint`` below, which follows the same layouts.
-The ``.npz`` format of ``diffusionsat_amd.weights`` is the documented, tested alternative.
+UNVERIFIED AGAINST A TENSORFLOW-WRITTEN FILE -- and not verifiable here: no checkpoint ships with
+the reference (README.md:38-40 points to GitHub Releases) and TensorFlow is not installed, so the
+format knowledge is from the published TensorBundle / leveldb table layouts.  The tests read files
+produced by ``write_checkpoint`` below and by an independently written table writer in
+tests/test_tf_checkpoint.py that exercises what TensorFlow's own writer does and ours does not:
+prefix-shared keys between restart points, several data blocks, a second data shard, entries of
+other dtypes (the object graph string, optimizer slots) and missing model keys.  The ``.npz`` format
+of ``diffusionsat_amd.weights`` stays the documented, tested path; ``tools/export_tf_checkpoint.py``
+converts a checkpoint to it on a machine that has TensorFlow.
 """
 from __future__ import annotations
 
@@ -117,7 +121,19 @@ def _read_block(data: bytes, offset: int, size: int):
         pos += vlen
 
 
-def read_index(index_path: str) -> Dict[str, tuple]:
+def read_header(index_path: str) -> Dict[str, int]:
+    """BundleHeaderProto of the index (the entry under the empty key): num_shards=1, endianness=2."""
+    hdr = {"num_shards": 1, "endianness": 0}
+    for key, value in _iter_table(index_path):
+        if key == b"":
+            p = _parse_proto(value)
+            hdr["num_shards"] = p.get(1, [1])[0]
+            hdr["endianness"] = p.get(2, [0])[0]
+        break       # keys are sorted: the header, if present, is first
+    return hdr
+
+
+def _iter_table(index_path: str):
     with open(index_path, "rb") as f:
         data = f.read()
     if len(data) < FOOTER_LEN:
@@ -130,14 +146,19 @@ def read_index(index_path: str) -> Dict[str, tuple]:
     _, pos = _get_varint(footer, pos)
     idx_off, pos = _get_varint(footer, pos)
     idx_size, pos = _get_varint(footer, pos)
-    entries = {}
     for _, handle in _read_block(data, idx_off, idx_size):
         boff, p2 = _get_varint(handle, 0)
         bsize, _ = _get_varint(handle, p2)
         for key, value in _read_block(data, boff, bsize):
-            if key == b"":
-                continue   # BundleHeaderProto
-            entries[key.decode("utf-8")] = _parse_entry(value)
+            yield key, value
+
+
+def read_index(index_path: str) -> Dict[str, tuple]:
+    entries = {}
+    for key, value in _iter_table(index_path):
+        if key == b"":
+            continue   # BundleHeaderProto
+        entries[key.decode("utf-8")] = _parse_entry(value)
     return entries
 
 
@@ -165,6 +186,9 @@ def latest_checkpoint(model_path: str) -> Optional[str]:
 
 def read_tensors(prefix: str, wanted=None) -> Dict[str, np.ndarray]:
     entries = read_index(prefix + ".index")
+    hdr = read_header(prefix + ".index")
+    if hdr["endianness"] != 0:
+        raise ValueError("%s: big-endian tensor bundle" % prefix)
     out = {}
     shards = {}
     for key, (dtype, shape, shard, offset, size) in entries.items():
@@ -173,7 +197,7 @@ def read_tensors(prefix: str, wanted=None) -> Dict[str, np.ndarray]:
         if dtype not in (DT_FLOAT, DT_INT64):
             continue
         if shard not in shards:
-            n = 1 + max(e[2] for e in entries.values())
+            n = max(hdr["num_shards"], 1 + max(e[2] for e in entries.values()))
             shards[shard] = np.memmap("%s.data-%05d-of-%05d" % (prefix, shard, n), dtype=np.uint8, mode="r")
         raw = bytes(shards[shard][offset:offset + size])
         arr = np.frombuffer(raw, dtype="<f4" if dtype == DT_FLOAT else "<i8")
@@ -181,13 +205,22 @@ def read_tensors(prefix: str, wanted=None) -> Dict[str, np.ndarray]:
     return out
 
 
-def load_queriesat_weights(model_path: str, layout=None) -> Optional[WeightSet]:
+last_restore_report: Dict[str, list] = {"restored": [], "missing": [], "unused": []}
+
+
+def load_queriesat_weights(model_path: str, layout=None, base: Optional[WeightSet] = None) -> Optional[WeightSet]:
     """Weights of the five MLPs from the latest checkpoint under ``model_path`` (or None if there
-    is none).  Missing optimizer slots etc. are ignored, like ``expect_partial()``."""
+    is none).  The reference restores with ``.expect_partial()`` (satuniformity/DiffusionSampler.py:220):
+    keys of the file the model does not have (optimizer slots, ``step``, the object graph) are ignored,
+    and model variables the file lacks silently keep their initial values.  The same here when ``base``
+    (the model's freshly initialised weights) is given -- ``last_restore_report`` then lists what was
+    restored, what stayed at its initial value and which float tensors of the file went unused; without
+    ``base`` a missing model variable raises KeyError."""
     prefix = latest_checkpoint(model_path) if model_path else None
     if prefix is None:
         return None
     tensors = read_tensors(prefix)
+    report = {"restored": [], "missing": [], "unused": []}
     ws: WeightSet = {}
     for name, dims in layer_dims(layout):
         layers = []
@@ -195,12 +228,24 @@ def load_queriesat_weights(model_path: str, layout=None) -> Optional[WeightSet]:
             kk = "model/%s/dense_layers/%d/kernel%s" % (name, i, KEY_SUFFIX)
             bk = "model/%s/dense_layers/%d/bias%s" % (name, i, KEY_SUFFIX)
             if kk not in tensors or bk not in tensors:
-                raise KeyError("checkpoint %s lacks %s (found %d tensors)" % (prefix, kk, len(tensors)))
-            w, b = tensors[kk], tensors[bk]
+                if base is None:
+                    raise KeyError("checkpoint %s lacks %s (found %d tensors)" % (prefix, kk, len(tensors)))
+                bw, bb = base[name][i]
+                w = tensors.get(kk, np.asarray(bw, np.float32))
+                b = tensors.get(bk, np.asarray(bb, np.float32))
+                report["missing"] += [k for k in (kk, bk) if k not in tensors]
+                report["restored"] += [k for k in (kk, bk) if k in tensors]
+            else:
+                w, b = tensors[kk], tensors[bk]
+                report["restored"] += [kk, bk]
             if w.shape != (fi, fo) or b.shape != (fo,):
                 raise ValueError("%s: kernel %s / bias %s, expected (%d,%d)/(%d,)" % (kk, w.shape, b.shape, fi, fo, fo))
             layers.append((w.astype(np.float32), b.astype(np.float32)))
         ws[name] = layers
+    used = set(report["restored"])
+    report["unused"] = sorted(k for k in tensors if k not in used)
+    last_restore_report.clear()
+    last_restore_report.update(report)
     return ws
 
 
