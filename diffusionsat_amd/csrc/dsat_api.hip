@@ -605,6 +605,9 @@ struct dsat_session {
     // select/SAT workgroups {graph, part, parts, 0}
     std::vector<int32_t> h_sel_tab;
     int32_t* sel_tab = nullptr;
+    // packed assignments: graph g's bits (bit i <-> its variable i, little-endian) start at byte h_pack_off[g]
+    std::vector<int32_t> h_pack_off;
+    int32_t* pack_off = nullptr;
     int n_sel = 0, sel_zero = 0;
     long long* stamps = nullptr;   // [3][4096][8] when DSAT_STAMPS=1
     RoundArgs ra1, ra2, ra3;   // templates: per-launch fields (round, tail, ...) are patched in
@@ -677,6 +680,7 @@ static void carve(dsat_session* s, Slab& sl) {
     }
     s->sel_tab = sl.take<int32_t>(s->h_sel_tab.size());
     s->vmeta4 = sl.take<int32_t>(s->h_vmeta4.size());
+    s->pack_off = sl.take<int32_t>(s->h_pack_off.size());
     s->vmeta = sl.take<int32_t>(s->h_vmeta.size());
     s->vgseg = sl.take<int32_t>(s->h_vgseg.size());
     s->cmeta = sl.take<int32_t>(s->h_cmeta.size());
@@ -935,6 +939,9 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             }
         }
         s->n_sel = (int)(s->h_sel_tab.size() / 4);
+        s->h_pack_off.assign(g->G + 1, 0);
+        for (int gi = 0; gi < g->G; ++gi)
+            s->h_pack_off[gi + 1] = s->h_pack_off[gi] + (g->h_var_seg[gi + 1] - g->h_var_seg[gi] + 7) / 8;
         // heavy literal rows: a "light" copy of the literal->clause CSR with those rows emptied, the
         // pieces heavy_gather_kernel sums, and per literal row where its pieces are
         if (const char* ev = getenv("DSAT_HEAVY_T")) s->heavy_t = std::max(1, atoi(ev));
@@ -985,8 +992,8 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         const size_t meta_bytes = (s->h_vmeta.size() + s->h_vgseg.size() + s->h_cmeta.size() + s->h_cgseg.size() +
                                    s->h_lrp_light.size() + s->h_lcl_light.size() + s->h_lhv.size() +
                                    s->h_pieces.size() + s->h_vgseg2.size() + s->h_vchunks.size() +
-                                   s->h_cgseg2.size() + s->h_cchunks.size() + s->h_sel_tab.size() + s->h_vmeta4.size()) *
-                                      sizeof(int32_t) + 20 * 64;
+                                   s->h_cgseg2.size() + s->h_cchunks.size() + s->h_sel_tab.size() + s->h_vmeta4.size() +
+                                   s->h_pack_off.size()) * sizeof(int32_t) + 24 * 64;
         char* stage = static_cast<char*>(arena->take_pin(meta_bytes));
         if (s->slab == nullptr || stage == nullptr) return arena_full(arena, "dsat_session_create_in");
         e = hipMemsetAsync(s->slab, 0, s->slab_bytes, st);
@@ -1022,6 +1029,7 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         }
         if (e2 == hipSuccess) e2 = cp(s->sel_tab, s->h_sel_tab);
         if (e2 == hipSuccess) e2 = cp(s->vmeta4, s->h_vmeta4);
+        if (e2 == hipSuccess) e2 = cp(s->pack_off, s->h_pack_off);
         if (e2 != hipSuccess) {
             (void)hipStreamDestroy(s->cap_stream);
             return hip_fail(e2, "segment upload", __FILE__, __LINE__);
@@ -1061,6 +1069,7 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         }
         if (e2 == hipSuccess) e2 = cp(s->sel_tab, s->h_sel_tab);
         if (e2 == hipSuccess) e2 = cp(s->vmeta4, s->h_vmeta4);
+        if (e2 == hipSuccess) e2 = cp(s->pack_off, s->h_pack_off);
         if (e2 != hipSuccess) {
             (void)hipFree(s->slab);
             return hip_fail(e2, "segment upload", __FILE__, __LINE__);
@@ -1844,6 +1853,64 @@ extern "C" int dsat_op_is_batch_sat(dsat_session* s, const float* logits, int32_
     DSAT_HIP(hipMemcpyAsync(&done, &s->ctl->done, sizeof(int), hipMemcpyDeviceToHost, st));
     DSAT_HIP(hipStreamSynchronize(st));
     *is_sat_out = done;
+    return DSAT_OK;
+}
+
+namespace dsat {
+__global__ void graph_sat_flags_kernel(const int32_t* __restrict__ graph_unsat, uint8_t* __restrict__ out, int G) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < G) out[g] = graph_unsat[g] == 0 ? 1 : 0;
+}
+}  // namespace dsat
+
+extern "C" int dsat_op_is_graph_sat(dsat_session* s, const float* logits, uint8_t* sat_out, void* stream) {
+    DSAT_REQUIRE(s && logits && sat_out, DSAT_E_INVALID, "dsat_op_is_graph_sat: null argument");
+    DSAT_ON_DEVICE(s, "dsat_op_is_graph_sat");
+    const dsat_graph* g = s->g;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = std::max(g->N, g->G);
+    hipLaunchKernelGGL(dsat::round_assign_kernel, dim3((n + 255) / 256), dim3(256), 0, st, logits, s->assign,
+                       s->graph_unsat, g->N, g->G, s->ctl);
+    launch_sat_check(g, s->assign, s->graph_unsat, s->ctl, 0, 0, st);
+    hipLaunchKernelGGL(dsat::graph_sat_flags_kernel, dim3((g->G + 255) / 256), dim3(256), 0, st, s->graph_unsat,
+                       sat_out, g->G);
+    DSAT_HIP(hipGetLastError());
+    return DSAT_OK;
+}
+
+namespace dsat {
+// one workgroup per graph: byte j of the graph's packed assignment = variables 8j .. 8j+7, bit k <-> variable 8j+k
+__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t* __restrict__ assign,
+                                                        const int32_t* __restrict__ vseg,
+                                                        const int32_t* __restrict__ pack_off,
+                                                        uint8_t* __restrict__ out) {
+    const int g = blockIdx.x;
+    const int v0 = vseg[g], v1 = vseg[g + 1];
+    const int nbytes = pack_off[g + 1] - pack_off[g];
+    for (int j = threadIdx.x; j < nbytes; j += blockDim.x) {
+        unsigned b = 0;
+        for (int k = 0; k < 8; ++k) {
+            const int v = v0 + 8 * j + k;
+            if (v < v1 && assign[v] != 0) b |= 1u << k;
+        }
+        out[pack_off[g] + j] = (uint8_t)b;
+    }
+}
+}  // namespace dsat
+
+extern "C" int64_t dsat_session_packed_bytes(const dsat_session* s, int32_t* offsets_out) {
+    if (!s) return -1;
+    if (offsets_out)
+        for (size_t i = 0; i < s->h_pack_off.size(); ++i) offsets_out[i] = s->h_pack_off[i];
+    return s->h_pack_off.empty() ? 0 : (int64_t)s->h_pack_off.back();
+}
+
+extern "C" int dsat_op_pack_assignment(dsat_session* s, const uint8_t* assignment, uint8_t* packed_out, void* stream) {
+    DSAT_REQUIRE(s && assignment && packed_out, DSAT_E_INVALID, "dsat_op_pack_assignment: null argument");
+    DSAT_ON_DEVICE(s, "dsat_op_pack_assignment");
+    hipLaunchKernelGGL(dsat::pack_bits_kernel, dim3(s->g->G), dim3(256), 0, (hipStream_t)stream, assignment,
+                       s->g->var_seg, s->pack_off, packed_out);
+    DSAT_HIP(hipGetLastError());
     return DSAT_OK;
 }
 

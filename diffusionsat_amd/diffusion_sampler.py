@@ -135,13 +135,14 @@ class DiffusionSampler:
     def batch(self) -> Batch:
         return self.inputs.batch
 
-    def _decode(self, assignment: np.ndarray, copies: int, counts: Dict[int, int], still_needed: int):
+    def _decode(self, packed: np.ndarray, copies: int, counts: Dict[int, int], still_needed: int):
         """Per-graph loop of ``samples`` (:283-307): int-encode (bit i <-> x_{i+1}), re-check."""
         total = sat = 0
         n = self.n_vars
         asgn = VariableAssignment(n_vars=n, clauses=self.clauses)
+        bits = np.unpackbits(packed.reshape(copies, -1), axis=1, bitorder="little")[:, :n]
         for i in range(copies):
-            asgn.assign_all_from_bit_list(assignment[i * n:(i + 1) * n])
+            asgn.assign_all_from_bit_list(bits[i])
             total += 1
             if asgn.satisfiable():
                 sat += 1
@@ -152,14 +153,15 @@ class DiffusionSampler:
                     break
         return total, sat, still_needed
 
-    def _decode_flags(self, assignment: np.ndarray, solved: np.ndarray, copies: int, counts: Dict[int, int],
+    def _decode_flags(self, packed: np.ndarray, solved: np.ndarray, copies: int, counts: Dict[int, int],
                       still_needed: int):
         """Same result as ``_decode`` without the per-copy Python SAT check: the device already
         evaluated every copy's clauses on exactly these bits (``solved``: the per-graph flag of
         ``dsat_sample`` -- a copy is frozen at the step that satisfied it, so flag == satisfiable);
-        the bits are packed little-endian, bit i <-> x_{i+1} (utils/VariableAssignment.py:63-69)."""
-        n, g = self.n_vars, copies
-        packed = np.packbits(assignment[: g * n].reshape(g, n).astype(np.uint8), axis=1, bitorder="little")
+        the bits arrive packed by the device, little-endian, bit i <-> x_{i+1}
+        (utils/VariableAssignment.py:63-69; ``dsat_op_pack_assignment``)."""
+        g = copies
+        packed = packed.reshape(g, -1)
         total = sat = 0
         for i in range(g):
             total += 1
@@ -193,13 +195,14 @@ class DiffusionSampler:
         with torch.cuda.stream(stream):
             out = sess.sample(diffusion_steps, test_rounds, seed=seed, early_exit=True,
                               want_solved_fraction=False, self_conditioning=self_supervised)
+            out["packed"] = sess.pack_assignment(out["assignment"])       # copies * ceil(n/8) bytes cross PCIe
         return stream, out
 
     def _collect(self, handle):
-        """Wait for a launched batch: (assignment uint8 [copies*n_vars], solved bool [copies])."""
+        """Wait for a launched batch: (packed bits uint8 [copies * ceil(n_vars/8)], solved bool [copies])."""
         stream, out = handle
         stream.synchronize()
-        return out["assignment"].cpu().numpy(), out["solved"].cpu().numpy() > 0
+        return out["packed"].cpu().numpy(), out["solved"].cpu().numpy() > 0
 
     # -- the reference surface ---------------------------------------------------------------------
     def samples(self, n_samples: int) -> Dict[int, int]:
@@ -242,11 +245,11 @@ class DiffusionSampler:
                 pending.append((copies, self._launch(it, copies, seed)))
                 it += 1
             copies, handle = pending.pop(0)
-            assignment, solved = self._collect(handle)
+            packed, solved = self._collect(handle)
             if self.host_recheck:
-                t, s, needed = self._decode(assignment, copies, counts, needed)
+                t, s, needed = self._decode(packed, copies, counts, needed)
             else:
-                t, s, needed = self._decode_flags(assignment, solved, copies, counts, needed)
+                t, s, needed = self._decode_flags(packed, solved, copies, counts, needed)
             total += t
             sat += s
         for _, handle in pending:                           # drain what was launched ahead

@@ -164,10 +164,10 @@ class QuerySAT:
         return self.diffusion_step(adj_matrix, clauses_graph, variables_graph, solutions, noise_scale, noisy_num,
                                    denoised_num=denoised_num, **kw)
 
-    def predict_step(self, adj_matrix: GraphInputs, clauses_graph=None, variables_graph=None, solutions=None):
-        """model/query_sat.py:419-451 with prediction_tries == 1: ``call(training=False)`` where
-        noise_scale ~ U(0,1) (:144) and noisy_num = construct_training_input(random labels, noise)
-        (:76-82, :214); the host draws those three values, the rounds run on the device."""
+    def _predict_once(self, adj_matrix: GraphInputs):
+        """``call(training=False)`` as predict_step makes it (model/query_sat.py:421, :133-184): noise_scale
+        ~ U(0,1) (:144), random labels (:145), noisy_num = construct_training_input(labels, noise) (:76-82,
+        :214); the host draws those three values, the rounds run on the device."""
         n = adj_matrix.n_vars
         rng = np.random.default_rng(self._seed + 7919 * (self._calls + 1))
         noise_scale = float(rng.random())
@@ -180,6 +180,26 @@ class QuerySAT:
         return self.diffusion_step(adj_matrix, noise_scale=noise_scale,
                                    noisy_num=torch.from_numpy(noisy).to(self.device),
                                    labels=torch.from_numpy(labels).to(self.device))
+
+    def predict_step(self, adj_matrix: GraphInputs, clauses_graph=None, variables_graph=None, solutions=None):
+        """model/query_sat.py:419-451.  ``prediction_tries`` == 1: one call.  Otherwise (:423-443) the model is
+        run ``prediction_tries`` times; a graph keeps the prediction of the first try that satisfies all its
+        clauses (``is_graph_sat``, utils/sat.py:165-180), graphs never solved end with zeros, as in the
+        reference (``final_predictions`` starts at zero and only solved graphs are added)."""
+        if self.prediction_tries == 1:
+            return self._predict_once(adj_matrix)
+        sess = self._session(adj_matrix)
+        gid = torch.from_numpy(adj_matrix.batch.var_graph_id.astype(np.int64)).to(self.device)
+        final = torch.zeros(adj_matrix.n_vars, dtype=torch.float32, device=self.device)
+        solved = torch.zeros(adj_matrix.n_graphs, dtype=torch.float32, device=self.device)
+        out = None
+        for _ in range(int(self.prediction_tries)):
+            out = self._predict_once(adj_matrix)
+            sat = sess.op_is_graph_sat(out["prediction"].contiguous()).to(torch.float32)
+            new = torch.clamp(sat - solved, 0, 1)                 # :433  graphs solved by this try for the first time
+            final += out["prediction"] * new[gid]                # :435-436
+            solved = solved + new                                 # :437
+        return {"steps_taken": out["steps_taken"], "loss": out["loss"], "prediction": final}
 
     def get_config(self):
         return {"model": self.__class__.__name__, "feature_maps": self.feature_maps,

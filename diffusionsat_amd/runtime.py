@@ -327,6 +327,30 @@ class Session:
         return out.value
 
     @_on_device
+    def op_is_graph_sat(self, logits) -> torch.Tensor:
+        """``is_graph_sat`` (utils/sat.py:165-180): uint8 [G], 1 = the graph's clauses are all satisfied."""
+        out = torch.empty(self.graph.n_graphs, dtype=torch.uint8, device=self.device)
+        _lib.check(_lib.load().dsat_op_is_graph_sat(self.handle, _ptr(logits, torch.float32, self.graph.n_vars, "logits"),
+                                                    _ptr(out), _stream(self.device)))
+        return out
+
+    def packed_offsets(self) -> np.ndarray:
+        """Byte offsets [G+1] of the graphs inside a packed assignment (``dsat_session_packed_bytes``)."""
+        off = np.zeros(self.graph.n_graphs + 1, dtype=np.int32)
+        _lib.load().dsat_session_packed_bytes(self.handle, off.ctypes.data_as(C.c_void_p))
+        return off
+
+    @_on_device
+    def pack_assignment(self, assignment: torch.Tensor) -> torch.Tensor:
+        """uint8 [N] assignment -> little-endian packed bits per graph (bit i <-> x_{i+1}), on the device."""
+        lib = _lib.load()
+        total = int(lib.dsat_session_packed_bytes(self.handle, None))
+        out = torch.empty(total, dtype=torch.uint8, device=self.device)
+        _lib.check(lib.dsat_op_pack_assignment(self.handle, _ptr(assignment, torch.uint8, self.graph.n_vars, "assignment"),
+                                               _ptr(out), _stream(self.device)))
+        return out
+
+    @_on_device
     def op_rng(self, seed: int, step_index: int, rounds: int):
         lib = _lib.load()
         n = self.graph.n_vars

@@ -232,6 +232,18 @@ int dsat_op_pair_norm(dsat_session* s, int32_t side, const float* x, float* y, v
 /* is_batch_sat (utils/sat.py:118-124) of prediction logits[N]; result (0/1) to
  * host `is_sat_out`; synchronises. */
 int dsat_op_is_batch_sat(dsat_session* s, const float* logits, int32_t* is_sat_out, void* stream);
+/* is_graph_sat (utils/sat.py:165-180) of prediction logits[N]: sat_out dev uint8 [G], 1 = every clause
+ * of the graph is satisfied by round(sigmoid(logits)) (the per-graph form predict_step uses when
+ * prediction_tries > 1, model/query_sat.py:423-443).  Stream-ordered. */
+int dsat_op_is_graph_sat(dsat_session* s, const float* logits, uint8_t* sat_out, void* stream);
+/* The int encoding of a sampled assignment (utils/VariableAssignment.py:63-69: bit i <-> x_{i+1}) packed
+ * on the device, so that samples() (satuniformity/DiffusionSampler.py:283-307) copies G * ceil(n/8)
+ * bytes instead of one byte per variable: graph g's bits, little-endian, occupy bytes
+ * [offsets[g], offsets[g+1]) of packed_out.  dsat_session_packed_bytes returns the total size and, when
+ * offsets_out (host int32 [G+1]) is not NULL, the offsets.  assignment dev uint8 [N] as dsat_sample
+ * returns it; packed_out dev uint8 [total].  Stream-ordered. */
+int64_t dsat_session_packed_bytes(const dsat_session* s, int32_t* offsets_out);
+int dsat_op_pack_assignment(dsat_session* s, const uint8_t* assignment, uint8_t* packed_out, void* stream);
 /* Philox draws as the device path makes them (normal [rounds,N,4]; labels [N];
  * uniform [N]) for a given (seed, step_index); any output may be NULL. */
 int dsat_op_rng(dsat_session* s, uint64_t seed, uint32_t step_index, int32_t rounds,

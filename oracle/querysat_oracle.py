@@ -196,6 +196,17 @@ def is_batch_sat(predictions, cl_adj):
     return clauses_sat.min() if clauses_sat.size else dt(1)
 
 
+def is_graph_sat(predictions, adj, clauses_graph):
+    """utils/sat.py:165-180: per graph, 1 when every clause is satisfied by round(sigmoid(predictions))."""
+    dt = predictions.dtype.type
+    variables = np.round(sigmoid(predictions)).reshape(-1, 1)
+    literals = np.concatenate([variables, dt(1) - variables], axis=0)
+    clauses_sat = np.clip(adj.T @ literals, 0, 1)
+    in_g = clauses_graph @ clauses_sat
+    total = np.asarray(clauses_graph.sum(axis=1)).reshape(-1, 1)
+    return np.clip(in_g + 1 - total, 0, 1)[:, 0]
+
+
 def distribution_at_time(x, t):
     """model/query_sat.py:66-68."""
     return x * (1 - t) + t / 2

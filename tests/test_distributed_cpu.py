@@ -77,7 +77,8 @@ class _FakeDeviceSampler:
         for i in range(copies):
             va.assign_all_from_bit_list(bits[i * self.n_vars:(i + 1) * self.n_vars])
             solved[i] = va.satisfiable()
-        return bits, solved
+        packed = np.packbits(bits.reshape(copies, self.n_vars), axis=1, bitorder="little")
+        return packed.reshape(-1), solved
 
 
 def _make_fake_sampler(path, rank, world):

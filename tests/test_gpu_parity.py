@@ -306,3 +306,70 @@ def test_facade_predict_step_and_self_conditioning(rt):
     ref2 = O.diffusion_step(ws, data, np.float32(0.3), noisy, d["normal"], d["labels"], R, early_exit=True,
                             dt=np.float32, denoised_num=den)
     _close(out2["prediction"].cpu().numpy(), ref2["prediction"], 0, 5e-4)
+
+
+def test_predict_step_with_several_tries_and_is_graph_sat(rt):
+    """QuerySAT.predict_step with prediction_tries > 1 (model/query_sat.py:423-443): each try is a fresh
+    call; a graph keeps the prediction of the first try that satisfies it (is_graph_sat,
+    utils/sat.py:165-180), unsolved graphs stay at zero.  Tiny formulas so that random weights do solve
+    some graphs; the host draws and device Philox normals are reproduced on the oracle side."""
+    from diffusionsat_amd.batch import make_batch
+    from diffusionsat_amd.query_sat import GraphInputs, QuerySAT
+    from oracle import philox
+    insts = [(3, [[1, 2], [-1, 3]]), (4, [[1, -2, 3], [2, 4], [-3, -4]]), (2, [[1], [-1]]), (3, [[1, -1], [2, -2, 3]])]
+    batch = make_batch(insts)
+    data = O.create_adj_matrices(insts)
+    ws = oracle_weights(4)
+    R, seed, tries = 6, 9, 4
+    model = QuerySAT(optimizer=None, test_rounds=R, seed=seed)
+    model.set_weights(ws)
+    model.prediction_tries = tries
+    gi = GraphInputs(batch)
+    out = model.predict_step(gi)
+    n, G = batch.n_vars, batch.n_graphs
+    vmask = data["variables_mask"]
+    final = np.zeros(n, np.float32)
+    solved = np.zeros(G, np.float32)
+    adj = data["adjacency_matrix"]
+    for call in range(1, tries + 1):
+        rng = np.random.default_rng(seed + 7919 * call)
+        noise_scale = float(rng.random())
+        labels = rng.integers(0, 2, n).astype(np.int32)
+        one_hot = np.stack([1 - labels, labels], axis=1).astype(np.float32)
+        t = np.float32(noise_scale) ** np.float32(0.5)
+        rounded = np.floor((one_hot * (1 - t) + t / 2)[:, 0:1] + rng.random((n, 1)).astype(np.float32))
+        noisy = np.concatenate([rounded, 1 - rounded], axis=1).astype(np.float32)
+        ref = O.diffusion_step(ws, data, np.float32(noise_scale), noisy, philox.normal(seed, call, R, n), labels, R,
+                               early_exit=True, dt=np.float32)
+        sat = O.is_graph_sat(ref["prediction"].astype(np.float32), adj, data["clauses_graph_adj"])
+        new = np.clip(sat - solved, 0, 1)
+        final += ref["prediction"] * new[vmask]
+        solved += new
+        # the single operator on the same logits
+        s = model._session(gi)
+        got = s.op_is_graph_sat(_dev(ref["prediction"].astype(np.float32))).cpu().numpy()
+        assert np.array_equal(got, sat.astype(np.uint8))
+    assert solved[2] == 0 and solved[3] == 1            # x & -x is never solved, the tautology always is
+    _close(out["prediction"].cpu().numpy(), final, 0, 5e-4)
+    assert np.all(out["prediction"].cpu().numpy()[vmask == 2] == 0)
+
+
+def test_device_packed_assignment_bits(rt):
+    """dsat_op_pack_assignment: per graph, little-endian bits (bit i <-> x_{i+1}) -- the int encoding of
+    utils/VariableAssignment.py:63-69 as bytes; graphs of different sizes, sizes not multiples of 8."""
+    from diffusionsat_amd.dimacs import VariableAssignment
+    insts, batch, _ = make_all("ragged")
+    s = _session(rt, batch, oracle_weights(0))
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2, batch.n_vars).astype(np.uint8)
+    packed = s.pack_assignment(_dev(bits)).cpu().numpy()
+    off = s.packed_offsets()
+    assert off[-1] == packed.size == sum((n + 7) // 8 for n, _ in insts)
+    v0 = 0
+    for g, (n, clauses) in enumerate(insts):
+        chunk = packed[off[g]:off[g + 1]]
+        assert np.array_equal(chunk, np.packbits(bits[v0:v0 + n], bitorder="little"))
+        va = VariableAssignment(n_vars=n, clauses=clauses)
+        va.assign_all_from_bit_list(bits[v0:v0 + n])
+        assert int.from_bytes(chunk.tobytes(), "little") == int(va)          # the reference's int encoding
+        v0 += n
