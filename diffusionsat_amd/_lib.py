@@ -80,6 +80,7 @@ SIGNATURES = {
     "dsat_op_pack_assignment": (C.c_int, [_vp, _vp, _vp, _vp]),
     "dsat_op_rng": (C.c_int, [_vp, _u64, _u32, _i32, _vp, _vp, _vp, _vp]),
     "dsat_session_set_profile": (C.c_int, [_vp, _i32]),
+    "dsat_session_set_retire": (C.c_int, [_vp, _i32]),
     "dsat_session_set_tap": (C.c_int, [_vp, C.POINTER(Tap)]),
     "dsat_session_read_stamps": (C.c_int, [_vp, C.POINTER(_i64), _i64]),
     "dsat_session_profile": (C.c_int, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),

@@ -316,6 +316,21 @@ static int graph_create_impl(dsat_arena* arena, hipStream_t st, const int32_t* c
     g->h_c_rowptr.assign(clause_rowptr, clause_rowptr + C + 1);
     g->h_l_rowptr = l_rowptr;
     g->h_l_clause = l_clause;
+    {   // replicate batch? every graph the same formula up to the variable offset (early retirement needs it)
+        bool same = G >= 1 && N % G == 0 && C % G == 0;
+        const int np = same ? N / G : 0, mp = same ? C / G : 0;
+        for (int gi = 0; same && gi < G; ++gi) same = vseg[gi] == gi * np && cseg[gi] == gi * mp;
+        for (int c = mp; same && c < C; ++c) {
+            const int c0 = c % mp, gi = c / mp;
+            const int len = clause_rowptr[c + 1] - clause_rowptr[c];
+            same = len == clause_rowptr[c0 + 1] - clause_rowptr[c0];
+            for (int k = 0; same && k < len; ++k) {
+                const int32_t a = clause_lits[clause_rowptr[c] + k], b = clause_lits[clause_rowptr[c0] + k];
+                same = (a > 0) == (b > 0) && std::abs(a) - gi * np == std::abs(b);
+            }
+        }
+        g->identical_copies = same;
+    }
     hipError_t e = hipSuccess;
     if ((e = up(arena, st, &g->c_rowptr, clause_rowptr, (size_t)C + 1)) != hipSuccess ||
         (e = up(arena, st, &g->c_lit, c_lit.data(), (size_t)E)) != hipSuccess ||
@@ -567,6 +582,11 @@ struct dsat_session {
     int max_rounds = 0;
     bool tap_on = false;
     dsat_tap tap;                  // dsat_session_set_tap (parity tests)
+    // early retirement of solved copies (dsat_session_set_retire)
+    int retire = 0;
+    int32_t *lid = nullptr, *move_src = nullptr, *n_act_dev = nullptr;
+    float *x0b = nullptr, *x1b = nullptr;   // second x buffers (the survivors move between steps)
+    int32_t* n_act_host = nullptr;          // pinned
     int no_cn = 0;                 // DSAT_NO_CN (ablation): P2 finishes the clause PairNorm itself
     char* slab = nullptr;
     size_t slab_bytes = 0;
@@ -681,6 +701,8 @@ static void carve(dsat_session* s, Slab& sl) {
     s->sel_tab = sl.take<int32_t>(s->h_sel_tab.size());
     s->vmeta4 = sl.take<int32_t>(s->h_vmeta4.size());
     s->pack_off = sl.take<int32_t>(s->h_pack_off.size());
+    s->lid = sl.take<int32_t>(G); s->move_src = sl.take<int32_t>(G); s->n_act_dev = sl.take<int32_t>(4);
+    s->x0b = sl.take<float>(N); s->x1b = sl.take<float>(N);
     s->vmeta = sl.take<int32_t>(s->h_vmeta.size());
     s->vgseg = sl.take<int32_t>(s->h_vgseg.size());
     s->cmeta = sl.take<int32_t>(s->h_cmeta.size());
@@ -799,6 +821,7 @@ static bool plan_round(dsat_session* s) {
     a.pgl = s->pgl; a.out_logits = s->out_logits; a.best = s->best; a.graph_unsat = s->graph_unsat;
     a.assign = s->assign;
     a.N = g->N; a.C = g->C; a.G = g->G;
+    a.NL = g->N; a.CL = g->C;
     a.vgseg2 = s->n_vchunks > 0 ? s->vgseg2 : nullptr; a.psum2_v = s->psum2_v;
     a.cgseg2 = s->n_cchunks > 0 ? s->cgseg2 : nullptr; a.psum2_c = s->psum2_c;
     a.sel_tab = s->sel_tab; a.n_sel = s->n_sel; a.sel_zero = s->sel_zero;
@@ -1107,6 +1130,7 @@ extern "C" void dsat_session_destroy(dsat_session* s) {
     for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->cap_stream) (void)hipStreamDestroy(s->cap_stream);
+    if (s->n_act_host) (void)hipHostFree(s->n_act_host);
     if (s->arena != nullptr) s->arena->live--;
     else if (s->slab) (void)hipFree(s->slab);
     if (s->stamps) (void)hipFree(s->stamps);
@@ -1139,6 +1163,19 @@ extern "C" int dsat_session_set_tap(dsat_session* s, const dsat_tap* tap) {
                  "dsat_session_set_tap: round must be in [0, max_rounds of the session)");
     s->tap = *tap;
     s->tap_on = true;
+    return DSAT_OK;
+}
+
+extern "C" int dsat_session_set_retire(dsat_session* s, int32_t enable) {
+    DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_retire: null session");
+    if (!enable) { s->retire = 0; return DSAT_OK; }
+    DSAT_REQUIRE(s->g->identical_copies, DSAT_E_UNSUPPORTED,
+                 "dsat_session_set_retire: the batch is not a set of identical copies of one formula");
+    DSAT_REQUIRE(s->use_fused, DSAT_E_UNSUPPORTED, "dsat_session_set_retire: needs the fused round kernels");
+    DSAT_REQUIRE(s->n_sel == s->g->G && s->n_vchunks == 0 && s->n_cchunks == 0, DSAT_E_UNSUPPORTED,
+                 "dsat_session_set_retire: formula too large (its select / PairNorm work is split over workgroups)");
+    if (s->n_act_host == nullptr) DSAT_HIP(hipHostMalloc((void**)&s->n_act_host, 4 * sizeof(int32_t), hipHostMallocDefault));
+    s->retire = 1;
     return DSAT_OK;
 }
 
@@ -1379,7 +1416,7 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
 // Fused launch sequence: per round P1 -> [S of the previous round] -> P2 -> P3, then the tail
 // P1 (last round's PairNorm + logits) and the last S.
 static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int early_exit, float* trace_logits,
-                              bool prof) {
+                              bool prof, int act_graphs = -1) {
     Launcher L{s, st, prof};
     hipError_t lerr = hipSuccess;   // first launch failure of the sequence
     auto note = [&](hipError_t e) { if (lerr == hipSuccess && e != hipSuccess) lerr = e; };
@@ -1390,10 +1427,16 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         if (dst != nullptr && n > 0) note(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
     };
     RoundArgs a1 = s->ra1, a2 = s->ra2, a3 = s->ra3;
+    int actN = s->g->N, actC = s->g->C;
+    if (act_graphs >= 0) {   // early retirement: the batch is the first act_graphs copies (identical formulas)
+        const int np = s->g->N / s->g->G, mp = s->g->C / s->g->G;
+        actN = act_graphs * np; actC = act_graphs * mp;
+        for (RoundArgs* a : {&a1, &a2, &a3}) { a->N = actN; a->C = actC; a->G = act_graphs; a->n_sel = act_graphs; }
+    }
     a1.check_done = a2.check_done = a3.check_done = early_exit;
     a1.trace_logits = trace_logits;
     // the non-state columns of v1 (normal draw, noisy_num, noise_scale, denoised) of all rounds
-    L.run(KC_MISC, [&] { launch_aux(s->aux, s->g->N, rounds, s->in_noisy, s->ctl, st); });   // :214-219, :239
+    L.run(KC_MISC, [&] { launch_aux(s->aux, actN, rounds, s->in_noisy, s->ctl, st); });   // :214-219, :239
     for (int r = 0; r <= rounds; ++r) {
         a1.round = r;
         a1.tail = r == rounds;
@@ -1401,12 +1444,12 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         const size_t half = std::max<size_t>(s->h_ctile_seg.empty() ? 1 : s->h_ctile_seg.back(), 1) * F;
         // idle CUs of P1 finish the clause PairNorm of round r-1 (only worth it while the variable
         // tiles leave CUs idle; otherwise P2 does it in its prologue)
-        const int vtiles = (s->g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
+        const int vtiles = (actN + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
         // role B (output / query pair on 64-row tiles) in every launch but the tail, which is the pair's
         // output half alone
-        a1.pair_blocks = a1.tail ? 0 : s->pair_blocks;
+        a1.pair_blocks = (a1.tail || s->pair_blocks == 0) ? 0 : (actN + 63) / 64;
         const int free_cus = 256 - vtiles - a1.pair_blocks;
-        const int cn = (r > 0 && r < rounds && s->g->C > 0 && free_cus >= 8 && !s->no_cn) ? free_cus : 0;
+        const int cn = (r > 0 && r < rounds && actC > 0 && free_cus >= 8 && !s->no_cn) ? free_cus : 0;
         a1.cn_blocks = cn;
         float* vbuf[2] = {s->V, s->Vlog};   // carried state, double-buffered by round (Vlog is free on this path)
         a1.V_in = vbuf[(r & 1) ^ 1];
@@ -1419,7 +1462,7 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         if (r == rounds) {
             // R15-R17 of the last round (with early exit the earlier rounds' run inside P2)
             L.run(KC_SELECT_SAT, [&] {
-                launch_select_sat(s->g, s->sel_tab, s->n_sel, s->logits, s->ctl, s->pgl, s->best, s->out_logits,
+                launch_select_sat(s->g, s->sel_tab, act_graphs >= 0 ? act_graphs : s->n_sel, s->logits, s->ctl, s->pgl, s->best, s->out_logits,
                                   s->assign, s->graph_unsat, r - 1, early_exit, st);
             });
             break;
@@ -1589,6 +1632,76 @@ extern "C" int dsat_diffusion_step_self(dsat_session* s, float noise_scale, cons
                                steps_taken_out, stream);
 }
 
+namespace dsat {
+__global__ void iota_kernel(int32_t* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+}  // namespace dsat
+
+// diffusion() for a batch of identical copies with early retirement: after every denoising step the
+// copies that have been solved (frozen by the reference, DiffusionSampler.py:154-170, and never looked at
+// again, :181-184) leave the batch; the survivors move to the front and the next step's kernels run on
+// that prefix only.  One host synchronisation per step (the new batch size sizes the next launches).
+// Every copy's random draws are keyed by its original position, so its trajectory is the one it has
+// without retirement -- except that the batch-global early exit (is_batch_sat) now means "all copies
+// still in the batch are satisfied".
+static int sample_retire_impl(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed, int32_t early_exit,
+                              const float* uniform, const float* normal, const int32_t* labels,
+                              uint8_t* assignment_out, uint8_t* solved_out, float* prediction_steps_out,
+                              float* solved_fraction_out, hipStream_t st, bool self_conditioning) {
+    const dsat_graph* g = s->g;
+    const int G = g->G, np = g->N / G;
+    const size_t N = g->N;
+    Ctl c = base_ctl(1.f, 0, n_steps, rounds, seed);
+    c.inj_normal = normal; c.normal_step_stride = (int64_t)rounds * N * 4;
+    c.inj_labels = labels; c.labels_step_stride = (int64_t)N;
+    c.inj_uniform = uniform; c.uniform_step_stride = (int64_t)N;
+    c.pred_steps_out = prediction_steps_out;
+    c.lid = s->lid; c.n_per = np;
+    if (self_conditioning) { c.denoised = s->in_denoised; c.denoised_wr = s->in_denoised; c.denoised_from_step = 1; }
+    launch_ctl_set(s->ctl, c, st);
+    launch_sample_init(s->x0, s->x1, g->N, s->fixed_step, s->cum_acc, G, s->ctl, st);
+    hipLaunchKernelGGL(dsat::iota_kernel, dim3((G + 255) / 256), dim3(256), 0, st, s->lid, G);
+    if (prediction_steps_out != nullptr)
+        DSAT_HIP(hipMemsetAsync(prediction_steps_out, 0, (size_t)n_steps * N * sizeof(float), st));
+    float* x0[2] = {s->x0, s->x0b};
+    float* x1[2] = {s->x1, s->x1b};
+    int cur = 0, n_act = G;
+    for (int t = 0; t < n_steps && n_act > 0; ++t) {
+        launch_sample_pre_retire(x0[cur], x1[cur], s->in_noisy, n_act * np, s->ctl, rounds, st);
+        int rc = enqueue_step_fused(s, st, rounds, early_exit ? 1 : 0, nullptr, false, n_act);
+        if (rc != DSAT_OK) return rc;
+        launch_sample_post_retire(x0[cur], x1[cur], s->out_logits, s->graph_unsat, s->fixed_step, s->x_fixed,
+                                  n_act * np, (int64_t)N, s->ctl, st);
+        const bool last = t + 1 == n_steps;
+        launch_retire_plan(s->fixed_step, s->cum_acc, s->graph_unsat, s->lid, s->move_src, n_act, s->ctl, s->n_act_dev,
+                           last ? 0 : 1, st);
+        if (!last) {
+            launch_retire_move(x0[cur], x1[cur], x0[cur ^ 1], x1[cur ^ 1], s->move_src, s->n_act_dev, n_act, np, st);
+            cur ^= 1;
+            DSAT_HIP(hipMemcpyAsync(s->n_act_host, s->n_act_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            DSAT_HIP(hipStreamSynchronize(st));
+            n_act = s->n_act_host[0];
+        }
+    }
+    // n_act: the slots of the last executed step (their lid entries are intact), or 0 when every copy was
+    // solved before the last step; solved copies take their frozen bits, the others round(p_last)
+    const int n_left = n_act;
+    launch_sample_final_retire(s->out_logits, s->lid, n_left, np, s->fixed_step, s->x_fixed, assignment_out, (int)N,
+                               s->cum_acc, solved_out, G, st);
+    DSAT_HIP(hipGetLastError());
+    if (solved_fraction_out) {
+        std::vector<uint8_t> h(G);
+        DSAT_HIP(hipMemcpyAsync(h.data(), s->cum_acc, G, hipMemcpyDeviceToHost, st));
+        DSAT_HIP(hipStreamSynchronize(st));
+        double acc = 0;
+        for (uint8_t b : h) acc += b;
+        *solved_fraction_out = (float)(acc / (double)G);
+    }
+    return DSAT_OK;
+}
+
 static int sample_impl(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed, int32_t early_exit,
                        const float* uniform, const float* normal, const int32_t* labels,
                        uint8_t* assignment_out, uint8_t* solved_out, float* prediction_steps_out,
@@ -1600,6 +1713,10 @@ static int sample_impl(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_
     DSAT_REQUIRE(assignment_out != nullptr, DSAT_E_INVALID, "dsat_sample: assignment_out is required");
     DSAT_REQUIRE(!s->tap_on, DSAT_E_STATE, "dsat_sample: a debug tap is set (taps belong to dsat_diffusion_step)");
     { int rc = require_device(s->device, "dsat_sample"); if (rc != DSAT_OK) return rc; }
+    if (s->retire && !s->profile)
+        return sample_retire_impl(s, n_steps, rounds, seed, early_exit, uniform, normal, labels, assignment_out,
+                                  solved_out, prediction_steps_out, solved_fraction_out, (hipStream_t)stream,
+                                  self_conditioning);
     hipStream_t st = (hipStream_t)stream;
     const dsat_graph* g = s->g;
     const size_t N = g->N;

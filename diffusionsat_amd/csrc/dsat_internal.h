@@ -86,6 +86,7 @@ struct dsat_graph {
     std::vector<int32_t> h_var_seg, h_cl_seg;
     std::vector<int32_t> h_c_rowptr, h_l_rowptr;   // host copies for the per-tile records
     std::vector<int32_t> h_l_clause;               // host copy of the literal->clause lists (heavy-row split)
+    bool identical_copies = false;                 // every graph is the same formula (replicate batch)
 };
 
 namespace dsat {
@@ -134,7 +135,21 @@ struct Ctl {
     const float* denoised;       // optional [N]: self-conditioning input of diffusion_step_self (query_sat.py:217-218)
     float* denoised_wr;          // sampler with self_supervised: sigmoid(prediction) of this step (DiffusionSampler.py:110-113)
     uint32_t denoised_from_step; // the input is used from this step on (the sampler's first step has none)
+    // Early retirement of solved copies (dsat_session_set_retire): the batch is a prefix of `slots`;
+    // slot g holds the copy whose ORIGINAL position is lid[g].  Random draws, injected noise and the
+    // per-copy results are indexed by the original position, so a copy's trajectory does not depend
+    // on which slot it sits in.  lid == nullptr: slot == original position.
+    const int32_t* lid;
+    int32_t n_per;               // variables per copy
 };
+
+// original (logical) index of variable v of the active prefix
+__device__ __forceinline__ int logical_var(const Ctl* ctl, int v) {
+    const int32_t* lid = ctl->lid;
+    if (lid == nullptr) return v;
+    const int np = ctl->n_per, g = v / np;
+    return lid[g] * np + (v - g * np);
+}
 
 void launch_gemm(const GemmArgs& a, const int* done, hipStream_t st);
 
@@ -175,7 +190,8 @@ struct RoundArgs {
     const float *deg_w, *vdeg_w, *rev_w;
     const int32_t *vgseg, *cgseg;     // PairNorm partial-sum segments of each graph: [gseg[g], gseg[g+1])
     const int32_t *vmeta, *cmeta;     // per-tile records, TILE_META_INTS int32 each (see TileMetaDev)
-    int N, C, G;
+    int N, C, G;           // ACTIVE sizes (bounds, grids); with retirement a prefix of the batch
+    int NL, CL;            // layout sizes of the graph: literal rows are v / NL + v, the zero pad rows 2*NL / CL
     // state and intermediates (HBM)
     float *V, *Cs, *q, *sp, *lits, *closs4, *vla, *ncv, *newv, *logits, *psum_v;
     // clause column sums are read (previous round) and written (this round) by the same kernel,
@@ -296,6 +312,17 @@ void launch_sample_pre(float* x0, float* x1, float* noisy, int N, Ctl* ctl, int 
 void launch_sample_post(float* x0, float* x1, const float* pred, const dsat_graph* g,
                         const int32_t* graph_unsat, int32_t* fixed_step, float* x_fixed,
                         uint8_t* cum_acc, Ctl* ctl, hipStream_t st);
+void launch_sample_pre_retire(float* x0, float* x1, float* noisy, int N, Ctl* ctl, int rounds, hipStream_t st);
+void launch_sample_post_retire(float* x0, float* x1, const float* pred, const int32_t* graph_unsat,
+                               const int32_t* fixed_step, float* x_fixed, int N, int64_t n_full, const Ctl* ctl,
+                               hipStream_t st);
+void launch_retire_plan(int32_t* fixed_step, uint8_t* cum_acc, const int32_t* graph_unsat, int32_t* lid,
+                        int32_t* move_src, int n_act, Ctl* ctl, int32_t* n_act_out, int reorder, hipStream_t st);
+void launch_retire_move(const float* x0_in, const float* x1_in, float* x0_out, float* x1_out, const int32_t* move_src,
+                        const int32_t* n_new_p, int n_act_old, int n_per, hipStream_t st);
+void launch_sample_final_retire(const float* pred, const int32_t* lid, int n_act, int n_per,
+                                const int32_t* fixed_step, const float* x_fixed, uint8_t* assignment, int n_full,
+                                const uint8_t* cum_acc, uint8_t* solved, int G, hipStream_t st);
 void launch_sample_final(const float* pred, const dsat_graph* g, const int32_t* fixed_step,
                          const float* x_fixed, uint8_t* assignment, const uint8_t* cum_acc,
                          uint8_t* solved, hipStream_t st);

@@ -135,12 +135,14 @@ __global__ __launch_bounds__(256) void aux_kernel(float* __restrict__ aux, int N
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * rounds) return;
     const int r = (int)(i / N), n = (int)(i % N);
+    const int ln = logical_var(ctl, n);      // draws belong to the variable's original position (retirement)
     float z[4];
     if (ctl->inj_normal != nullptr) {
-        const float4 v = ld4(ctl->inj_normal + ctl->normal_step_stride * ctl->step + ((size_t)r * N + n) * 4);
+        const int64_t nl = ctl->lid != nullptr ? ctl->normal_step_stride / ((int64_t)4 * rounds) : N;   // full N
+        const float4 v = ld4(ctl->inj_normal + ctl->normal_step_stride * ctl->step + ((size_t)r * nl + ln) * 4);
         z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
     } else {
-        u32x4 c = {(uint32_t)n, (uint32_t)r, ctl->step, (uint32_t)STREAM_NORMAL};
+        u32x4 c = {(uint32_t)ln, (uint32_t)r, ctl->step, (uint32_t)STREAM_NORMAL};
         const u32x4 x = philox4x32_10(c, (uint32_t)ctl->seed, (uint32_t)(ctl->seed >> 32));
         box_muller(x.x, x.y, z[0], z[1]);
         box_muller(x.z, x.w, z[2], z[3]);
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void aux_kernel(float* __restrict__ aux, int N
     float* o = aux + i * AUX_W;
     st4(o, make_float4(z[0], z[1], z[2], z[3]));
     float d0 = 0.f, d1 = 0.f;
-    if (ctl->denoised != nullptr && ctl->step >= ctl->denoised_from_step) { d0 = ctl->denoised[n]; d1 = 1.f - d0; }   // query_sat.py:218
+    if (ctl->denoised != nullptr && ctl->step >= ctl->denoised_from_step) { d0 = ctl->denoised[ln]; d1 = 1.f - d0; }   // query_sat.py:218
     st4(o + 4, make_float4(noisy_num[2 * n], noisy_num[2 * n + 1], ctl->noise_scale, d0));
     st4(o + 8, make_float4(d1, 0.f, 0.f, 0.f));
     st4(o + 12, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -431,6 +433,176 @@ __global__ void sample_final_kernel(const float* __restrict__ pred, const int32_
         assignment[i] = (uint8_t)v;
     }
     if (i < G && solved != nullptr) solved[i] = cum_acc[i];
+}
+
+// ---------------------------------------------------------------- sampler with early retirement
+// The same steps for a batch of identical copies whose solved copies leave the batch between
+// denoising steps (satuniformity/DiffusionSampler.py:154-170 freezes them; their later predictions are
+// never used, :181-184).  The active copies are slots 0 .. n_act-1; lid[slot] = original position.
+// x0 / x1 / noisy are per slot; fixed_step, cum_acc, x_fixed, denoised are per ORIGINAL position.
+__global__ void sample_pre_retire_kernel(float* __restrict__ x0, float* __restrict__ x1,
+                                         float* __restrict__ noisy, int N, Ctl* __restrict__ ctl, int rounds) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = ctl->step;
+    if (n == 0) {
+        ctl->noise_scale = (float)(1.0 - (double)t / (double)ctl->n_steps);
+        ctl->done = 0;
+        ctl->steps_taken = rounds - 1;
+    }
+    if (n >= N) return;
+    const int ln = logical_var(ctl, n);
+    const float u = ctl->inj_uniform != nullptr ? ctl->inj_uniform[ctl->uniform_step_stride * t + ln]
+                                                : philox_uniform((uint32_t)ln, t, ctl->seed);
+    const float r = floorf(x0[n] + u);
+    noisy[2 * n] = r;
+    noisy[2 * n + 1] = 1.f - r;
+    x0[n] = r;
+    x1[n] = 1.f - r;
+}
+
+__global__ void sample_post_retire_kernel(float* __restrict__ x0, float* __restrict__ x1,
+                                          const float* __restrict__ pred, const int32_t* __restrict__ graph_unsat,
+                                          const int32_t* __restrict__ fixed_step, float* __restrict__ x_fixed,
+                                          int N, int64_t n_full, const Ctl* __restrict__ ctl) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t t = ctl->step;
+    const double nsd = 1.0 - (double)t / (double)ctl->n_steps;
+    const double inc = 1.0 / (double)ctl->n_steps;
+    const float logit = pred[n];
+    const float p = sigmoid_f(logit);
+    const int ln = logical_var(ctl, n);
+    if (ctl->pred_steps_out != nullptr) ctl->pred_steps_out[(size_t)t * n_full + ln] = logit;
+    if (ctl->denoised_wr != nullptr) ctl->denoised_wr[ln] = p;
+    const float t1 = powf((float)nsd, 0.5f);
+    const double rem = nsd - inc;
+    const float t2 = powf((float)(rem > 0.0 ? rem : 0.0), 0.5f);
+    const float xn0 = (1.f - p) * (1.f - t1) + t1 * 0.5f;
+    const float xn1 = p * (1.f - t1) + t1 * 0.5f;
+    const float alpha = (1.f - t1) / (1.f - t2);
+    const float ti = 1.f - alpha;
+    const float u0 = (x0[n] * (1.f - ti) + ti * 0.5f) * xn0;
+    const float u1 = (x1[n] * (1.f - ti) + ti * 0.5f) * xn1;
+    const float den = (u0 + u1) + 1e-8f;
+    x0[n] = u0 / den;
+    x1[n] = u1 / den;
+    const int g = n / ctl->n_per;
+    if (fixed_step[ctl->lid[g]] < 0 && graph_unsat[g] == 0) x_fixed[ln] = rintf(p);
+}
+
+// One workgroup: record the copies solved in this step, then plan the next step's batch: unsolved
+// slots keep their order and move to the front.  move_src[new slot] = old slot; lid is rewritten.
+__global__ __launch_bounds__(1024) void retire_plan_kernel(int32_t* __restrict__ fixed_step,
+                                                           uint8_t* __restrict__ cum_acc,
+                                                           const int32_t* __restrict__ graph_unsat,
+                                                           int32_t* __restrict__ lid, int32_t* __restrict__ move_src,
+                                                           int n_act, Ctl* ctl, int32_t* __restrict__ n_act_out,
+                                                           int reorder) {
+    __shared__ int s_keep[1024];
+    __shared__ int s_base;
+    const uint32_t t = ctl->step;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_act; c0 += 1024) {
+        const int sl = c0 + threadIdx.x;
+        int keep = 0, lg = -1;
+        if (sl < n_act) {
+            lg = lid[sl];
+            const bool sat = graph_unsat[sl] == 0;
+            if (sat) cum_acc[lg] = 1;
+            if (sat && fixed_step[lg] < 0) fixed_step[lg] = (int32_t)t;
+            keep = fixed_step[lg] < 0 ? 1 : 0;
+        }
+        s_keep[threadIdx.x] = keep;
+        __syncthreads();
+        // exclusive scan of the chunk by thread 0 .. simple and at most 1024 entries per chunk
+        if (threadIdx.x == 0) {
+            int run = s_base;
+            for (int i = 0; i < 1024; ++i) { const int k = s_keep[i]; s_keep[i] = run; run += k; }
+            s_base = run;
+        }
+        __syncthreads();
+        if (keep && reorder) move_src[s_keep[threadIdx.x]] = sl;
+        __syncthreads();
+    }
+    if (!reorder) {   // last step: only record what was solved; slots and lid stay as the step ran them
+        if (threadIdx.x == 0) { ctl->step = t + 1; *n_act_out = n_act; }
+        return;
+    }
+    // second pass: new lid from the old one through move_src (separate array: slots only move down)
+    __syncthreads();
+    const int n_new = s_base;
+    // lid[new] = lid[move_src[new]] with move_src[new] >= new: ascending order is safe per chunk of 1024
+    for (int c0 = 0; c0 < n_new; c0 += 1024) {
+        const int i = c0 + threadIdx.x;
+        int v = 0;
+        if (i < n_new) v = lid[move_src[i]];
+        __syncthreads();
+        if (i < n_new) lid[i] = v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        ctl->step = t + 1;
+        *n_act_out = n_new;
+    }
+}
+
+// x of the surviving copies to their new slots (other buffer: slots only move down, but in parallel)
+__global__ void retire_move_kernel(const float* __restrict__ x0_in, const float* __restrict__ x1_in,
+                                   float* __restrict__ x0_out, float* __restrict__ x1_out,
+                                   const int32_t* __restrict__ move_src, const int32_t* __restrict__ n_new_p, int n_per) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_new = *n_new_p;
+    if (i >= n_new * n_per) return;
+    const int g = i / n_per, k = i - g * n_per;
+    const int src = move_src[g] * n_per + k;
+    x0_out[i] = x0_in[src];
+    x1_out[i] = x1_in[src];
+}
+
+// predictions = round(p_last) for copies still in the batch, the frozen bits for solved ones (:181-184)
+__global__ void sample_final_retire_kernel(const float* __restrict__ pred, const int32_t* __restrict__ lid, int n_act,
+                                           int n_per, const int32_t* __restrict__ fixed_step,
+                                           const float* __restrict__ x_fixed, uint8_t* __restrict__ assignment,
+                                           int n_full, const uint8_t* __restrict__ cum_acc,
+                                           uint8_t* __restrict__ solved, int G) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_full && fixed_step[i / n_per] >= 0) assignment[i] = (uint8_t)x_fixed[i];
+    if (i < n_act * n_per) {
+        const int g = i / n_per, lg = lid[g];
+        if (fixed_step[lg] < 0) assignment[lg * n_per + (i - g * n_per)] = (uint8_t)rintf(sigmoid_f(pred[i]));
+    }
+    if (i < G && solved != nullptr) solved[i] = cum_acc[i];
+}
+
+void launch_sample_pre_retire(float* x0, float* x1, float* noisy, int N, Ctl* ctl, int rounds, hipStream_t st) {
+    hipLaunchKernelGGL(sample_pre_retire_kernel, dim3((N + 255) / 256 > 0 ? (N + 255) / 256 : 1), dim3(256), 0, st,
+                       x0, x1, noisy, N, ctl, rounds);
+}
+void launch_sample_post_retire(float* x0, float* x1, const float* pred, const int32_t* graph_unsat,
+                               const int32_t* fixed_step, float* x_fixed, int N, int64_t n_full, const Ctl* ctl,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(sample_post_retire_kernel, dim3((N + 255) / 256 > 0 ? (N + 255) / 256 : 1), dim3(256), 0, st,
+                       x0, x1, pred, graph_unsat, fixed_step, x_fixed, N, n_full, ctl);
+}
+void launch_retire_plan(int32_t* fixed_step, uint8_t* cum_acc, const int32_t* graph_unsat, int32_t* lid,
+                        int32_t* move_src, int n_act, Ctl* ctl, int32_t* n_act_out, int reorder, hipStream_t st) {
+    hipLaunchKernelGGL(retire_plan_kernel, dim3(1), dim3(1024), 0, st, fixed_step, cum_acc, graph_unsat, lid, move_src,
+                       n_act, ctl, n_act_out, reorder);
+}
+void launch_retire_move(const float* x0_in, const float* x1_in, float* x0_out, float* x1_out, const int32_t* move_src,
+                        const int32_t* n_new_p, int n_act_old, int n_per, hipStream_t st) {
+    const int64_t n = (int64_t)n_act_old * n_per;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(retire_move_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x0_in, x1_in, x0_out,
+                       x1_out, move_src, n_new_p, n_per);
+}
+void launch_sample_final_retire(const float* pred, const int32_t* lid, int n_act, int n_per,
+                                const int32_t* fixed_step, const float* x_fixed, uint8_t* assignment, int n_full,
+                                const uint8_t* cum_acc, uint8_t* solved, int G, hipStream_t st) {
+    const int n = n_full > G ? n_full : G;
+    hipLaunchKernelGGL(sample_final_retire_kernel, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0, st,
+                       pred, lid, n_act, n_per, fixed_step, x_fixed, assignment, n_full, cum_acc, solved, G);
 }
 
 void launch_sample_init(float* x0, float* x1, int N, int32_t* fixed_step, uint8_t* cum_acc, int G,

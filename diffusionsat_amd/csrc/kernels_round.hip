@@ -473,7 +473,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     constexpr int BM = ROUND_BM_VAR;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int N = a.N;
+    const int N = a.N, NL = a.NL;
     const int vtiles = (N + BM - 1) / BM;
     const int b = blockIdx.x;
     const bool roleA = b < vtiles, roleB = !roleA && b < vtiles + a.pair_blocks;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
                                              log1pf(expf(-fabsf(v.z))), log1pf(expf(-fabsf(v.w))));
                 stg4(sp + (size_t)n * F + col, make_float4(fmaxf(v.x, 0.f) + t.x, fmaxf(v.y, 0.f) + t.y,
                                                           fmaxf(v.z, 0.f) + t.z, fmaxf(v.w, 0.f) + t.w));
-                stg4(sp + (size_t)(N + n) * F + col, make_float4(fmaxf(-v.x, 0.f) + t.x, fmaxf(-v.y, 0.f) + t.y,
+                stg4(sp + (size_t)(NL + n) * F + col, make_float4(fmaxf(-v.x, 0.f) + t.x, fmaxf(-v.y, 0.f) + t.y,
                                                                 fmaxf(-v.z, 0.f) + t.z, fmaxf(-v.w, 0.f) + t.w));
             }
         };
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
                                              log1pf(expf(-fabsf(v.z))), log1pf(expf(-fabsf(v.w))));
                 stg4(sp + (size_t)n * F + col, make_float4(fmaxf(v.x, 0.f) + t.x, fmaxf(v.y, 0.f) + t.y,
                                                           fmaxf(v.z, 0.f) + t.z, fmaxf(v.w, 0.f) + t.w));
-                stg4(sp + (size_t)(N + n) * F + col, make_float4(fmaxf(-v.x, 0.f) + t.x, fmaxf(-v.y, 0.f) + t.y,
+                stg4(sp + (size_t)(NL + n) * F + col, make_float4(fmaxf(-v.x, 0.f) + t.x, fmaxf(-v.y, 0.f) + t.y,
                                                                 fmaxf(-v.z, 0.f) + t.z, fmaxf(-v.w, 0.f) + t.w));
             }
         };
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
         run_chain<1>(a.mlit, sX, ldx, sA, a.ld_a, sB, a.ld_b, wave, lane, [=](int row, int col, float4 v) {
             int n = tile_lo + row;
             NO_HOIST(n);
-            if (n < N && col < 2 * F) stg4(lits + ((size_t)(col < F ? n : N + n)) * F + (col & (F - 1)), v);
+            if (n < N && col < 2 * F) stg4(lits + ((size_t)(col < F ? n : NL + n)) * F + (col & (F - 1)), v);
         });
     }
     DSAT_STAMP(a, 4);
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
     constexpr int BM = 16 * RB;
     constexpr int ROWS = (BM + NT / 32 - 1) / (NT / 32);   // clause rows per half-wave
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int C = a.C, N = a.N;
+    const int C = a.C, NL = a.NL;
     const int tiles = (C + BM - 1) / BM;
     const bool extra = (int)blockIdx.x >= tiles;
     const int tile = extra ? 0 : xcd_tile(blockIdx.x, tiles);
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
         DSAT_STAMP_RT_BEGIN(a);
         DSAT_STAMP(a, 0);
         select_sat_body<NT>(blockIdx.x - tiles, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
-                            a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, N, a.round - 1, a.check_done,
+                            a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, NL, a.round - 1, a.check_done,
                             smem);
         DSAT_STAMP(a, 4);
         DSAT_STAMP_RT_END(a);
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
             }
             nmax = max(nmax, e1[u] - e0[u]);
         }
-        const unsigned zrow = 2u * (unsigned)N;   // the all-zero row of sp / lits
+        const unsigned zrow = 2u * (unsigned)NL;   // the all-zero row of sp / lits
         for (int off = 0; off < nmax; off += GJ) {   // branch-free, see the P3 gather
             unsigned l[U][GJ];
             float4 sv[U][GJ], lv[U][GJ];
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
 #endif
     constexpr int GJ = DSAT_GJ3;                // clause rows in flight per literal (x PASSES x 2 arrays)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int N = a.N;
+    const int N = a.N, NL = a.NL;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
     const TileMetaDev tm = load_meta(a.vmeta, tile);
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
         int* sIdx1 = sIdx0 + cap;
         const int nrows = tile_hi - tile_lo;
         const bool st0 = stage_csr(a.l_rowptr, a.l_clause, tile_lo, nrows, tm.e_base0, tm.e_end0, sPtr0, sIdx0, cap, tid);
-        const bool st1 = stage_csr(a.l_rowptr, a.l_clause, N + tile_lo, nrows, tm.e_base1, tm.e_end1, sPtr1, sIdx1, cap, tid);
+        const bool st1 = stage_csr(a.l_rowptr, a.l_clause, NL + tile_lo, nrows, tm.e_base1, tm.e_end1, sPtr1, sIdx1, cap, tid);
         const bool staged = st0 && st1;
         // rows that do not depend on the lists: q (half 0) and the carried state (half 1)
         float4 rowv[PASSES], qrow[PASSES];
@@ -825,10 +825,10 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
             wdeg[u] = 0.f; wv[u] = 0.f;
             hv[u] = make_int2(-1, 0);
             if (v < N) {
-                if (a.l_hv != nullptr) hv[u] = a.l_hv[v + half * N];
+                if (a.l_hv != nullptr) hv[u] = a.l_hv[v + half * NL];
                 qrow[u] = ld4(a.q + (size_t)v * F + sub * 4);
                 if (half == 1) rowv[u] = ld4(a.V + (size_t)v * F + sub * 4);
-                wdeg[u] = a.deg_w[v + half * N];
+                wdeg[u] = a.deg_w[v + half * NL];
                 wv[u] = a.vdeg_w[v];
             }
         }
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
                     const int* sp_ = half ? sPtr1 : sPtr0;
                     e0[u] = sp_[r]; e1[u] = sp_[r + 1];
                 } else {
-                    const int lit = tile_lo + r + half * N;
+                    const int lit = tile_lo + r + half * NL;
                     e0[u] = a.l_rowptr[lit]; e1[u] = a.l_rowptr[lit + 1];
                 }
             }
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
         // Branch-free: a conditional load would make the compiler wait for memory at every
         // join, serialising the rows.  List slots past a row's end read the all-zero row C
         // (dsat_api.hip carve), so nothing is masked; offsets are 32-bit (SGPR base + VGPR).
-        const unsigned zrow = (unsigned)a.C;
+        const unsigned zrow = (unsigned)a.CL;
         for (int off = 0; off < nmax; off += GJ) {
             unsigned ci[PASSES][GJ];
             float4 cv[PASSES][GJ], vv[PASSES][GJ];
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
             const float4 vls = make_float4(VL[u].x * dw, VL[u].y * dw, VL[u].z * dw, VL[u].w * dw);
             st4(sX + r * ldx + (half ? OFF_NEG : OFF_POS) + sub * 4, vls);
             if (a.tap_vloss != nullptr && tile_lo + r < N)
-                st4(a.tap_vloss + ((size_t)(tile_lo + r) + (size_t)half * N) * F + sub * 4, vls);
+                st4(a.tap_vloss + ((size_t)(tile_lo + r) + (size_t)half * NL) * F + sub * 4, vls);
             float4 Mo;
             Mo.x = __shfl_xor(M[u].x, 32); Mo.y = __shfl_xor(M[u].y, 32);
             Mo.z = __shfl_xor(M[u].z, 32); Mo.w = __shfl_xor(M[u].w, 32);
@@ -1073,9 +1073,9 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
     for (int v = v0 + tid; v < v1; v += NTH) {
         int label;
         if (ctl->inj_labels != nullptr) {
-            label = ctl->inj_labels[ctl->labels_step_stride * ctl->step + v];
+            label = ctl->inj_labels[ctl->labels_step_stride * ctl->step + logical_var(ctl, v)];
         } else {
-            u32x4 c = {(uint32_t)v, 0u, ctl->step, (uint32_t)STREAM_LABELS};
+            u32x4 c = {(uint32_t)logical_var(ctl, v), 0u, ctl->step, (uint32_t)STREAM_LABELS};
             label = (int)(philox4x32_10(c, (uint32_t)ctl->seed, (uint32_t)(ctl->seed >> 32)).x & 1u);
         }
         const float a = (float)label * (1.f - tl) + tl * 0.5f;

@@ -85,7 +85,8 @@ class DiffusionSampler:
 
     def __init__(self, model_path: Optional[str], dimacs_filename: str, device: str = "cuda:0", seed: int = 0,
                  rank: int = 0, world_size: int = 1, n_solutions: Optional[int] = None,
-                 test_solutions_multiplier_k: int = 10, copies_per_batch: Optional[int] = None):
+                 test_solutions_multiplier_k: int = 10, copies_per_batch: Optional[int] = None,
+                 retire_solved: bool = False):
         self.device = device
         self.model = QuerySAT(optimizer=None, test_rounds=test_rounds, device=device, seed=seed)
         self.restored = bool(model_path) and self.model.load_weights(model_path)
@@ -117,6 +118,10 @@ class DiffusionSampler:
         self.host_recheck = False
         # independent batches kept in flight by samples(); 1 = strictly one after the other
         self.batches_in_flight = 2
+        # drop a copy from its batch once it has been solved (``dsat_session_set_retire``): the remaining
+        # denoising steps run on fewer copies; results per copy as without it, except that the batch-global
+        # early exit then refers to the copies still in the batch
+        self.retire_solved = bool(retire_solved)
         self._inputs: Dict[int, GraphInputs] = {}     # copies -> device graph
         self._slots: Dict[int, list] = {}             # copies -> [(session, stream), ...]
 
@@ -184,6 +189,8 @@ class DiffusionSampler:
         while len(slots) < k:
             sess = runtime.Session(gi.graph, self.model.device_weights(), max_rounds=test_rounds,
                                    device=self.model.device)
+            if self.retire_solved:
+                sess.set_retire(True)
             slots.append((sess, torch.cuda.Stream(device=self.model.device)))
         return slots[:k]
 

@@ -365,6 +365,10 @@ class Session:
     def set_graph_replay(self, enable: bool):
         _lib.check(_lib.load().dsat_session_set_graph_replay(self.handle, int(enable)))
 
+    def set_retire(self, enable: bool):
+        """Drop solved copies from a batch of identical copies between denoising steps (``dsat_session_set_retire``)."""
+        _lib.check(_lib.load().dsat_session_set_retire(self.handle, int(enable)))
+
     def set_profile(self, enable: bool):
         _lib.check(_lib.load().dsat_session_set_profile(self.handle, int(enable)))
 

@@ -190,6 +190,17 @@ int dsat_sample(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed,
                 const int32_t* labels, uint8_t* assignment_out, uint8_t* solved_out,
                 float* prediction_steps_out, float* solved_fraction_out, void* stream);
 
+/* Early retirement for batches of identical copies of ONE formula (the sampler's batches,
+ * data/diffusion_sat_instances.py:80-94): with enable = 1, dsat_sample / dsat_sample_self drop a copy
+ * from the batch once it has been solved -- the reference freezes its bits at that step and never
+ * uses its later predictions (satuniformity/DiffusionSampler.py:154-170, :181-184) -- so the remaining
+ * denoising steps run on ever fewer copies.  A copy's random draws are keyed by its original position:
+ * its outputs are those of the non-retiring run, except that the batch-global early exit
+ * (is_batch_sat, model/query_sat.py:330-338) then refers to the copies still in the batch.  Costs one
+ * host synchronisation per denoising step.  DSAT_E_UNSUPPORTED when the graphs of the batch are not
+ * identical copies, or the formula is large enough to have its select / PairNorm work split. */
+int dsat_session_set_retire(dsat_session* s, int32_t enable);
+
 /* diffusion() with the reference's `self_supervised` switch on
  * (satuniformity/DiffusionSampler.py:21, :110-113): step t >= 1 runs diffusion_step_self with
  * sigmoid(prediction) of step t-1 as denoised_num; step 0 has no previous prediction (:93).

@@ -231,3 +231,76 @@ def test_large_graph_select_parts_and_early_exit(rt):
             assert bool(smp["solved"].cpu().numpy()[0]) == want_exit
             assert smp["solved_fraction"] == (1.0 if want_exit else 0.0)
             _host_check(batch, smp["assignment"].cpu().numpy(), smp["solved"].cpu().numpy() > 0)
+
+
+# ------------------------------------------------------------------------------------------ N1: early retirement
+def _easy_formula(n=16, m=64, k=6, seed=3):
+    rng = np.random.default_rng(seed)
+    return n, [[int(v + 1) if rng.random() < 0.5 else -int(v + 1) for v in rng.choice(n, size=k, replace=False)]
+               for _ in range(m)]
+
+
+def test_early_retirement_matches_the_full_batch(rt):
+    """Solved copies leave the batch between denoising steps (dsat_session_set_retire).  A formula of 16
+    variables and 64 clauses makes every copy exactly one variable tile and one clause tile, so a copy's
+    arithmetic does not depend on the slot it occupies: assignments and solved flags are BITWISE those of
+    the non-retiring run (early exit off: the batch-global break is the one documented difference).
+    Width-6 clauses: about a third of the random roundings satisfy the formula, so copies retire at
+    every step."""
+    from diffusionsat_amd.batch import make_batch
+    n, clauses = _easy_formula()
+    G, T, R = 45, 6, 4
+    batch = make_batch([(n, clauses)] * G)
+    ws = oracle_weights(2)
+    g, w = rt.Graph(batch), rt.Weights(ws)
+    full = rt.Session(g, w, max_rounds=R)
+    a = full.sample(T, R, seed=5, early_exit=False)
+    ret = rt.Session(g, w, max_rounds=R)
+    ret.set_retire(True)
+    b = ret.sample(T, R, seed=5, early_exit=False)
+    sa, sb = a["solved"].cpu().numpy(), b["solved"].cpu().numpy()
+    assert 5 < sa.sum() < G                                    # some solved (at different steps), some never
+    assert np.array_equal(sa, sb)
+    assert torch.equal(a["assignment"], b["assignment"])
+    assert abs(a["solved_fraction"] - b["solved_fraction"]) < 1e-7
+    _host_check(batch, b["assignment"].cpu().numpy(), sb > 0)
+    again = ret.sample(T, R, seed=5, early_exit=False)
+    assert torch.equal(again["assignment"], b["assignment"])
+    # injected noise is looked up by a copy's original position too
+    d = draws(batch.n_vars, R, steps=T, seed=9)
+    kw = dict(uniform=_dev(d["uniform"].reshape(T, -1)), normal=_dev(d["normal"]), labels=_dev(d["labels"]))
+    a2 = full.sample(T, R, seed=0, early_exit=False, **kw)
+    b2 = ret.sample(T, R, seed=0, early_exit=False, **kw)
+    assert torch.equal(a2["assignment"], b2["assignment"]) and torch.equal(a2["solved"], b2["solved"])
+    # every copy solved at once (a tautology): the loop ends after the first step
+    taut = make_batch([(16, [[1 + (i % 16), -(1 + (i % 16)), 1 + ((i + 3) % 16)] for i in range(64)])] * 20)
+    st = rt.Session(rt.Graph(taut), w, max_rounds=R)
+    st.set_retire(True)
+    o = st.sample(T, R, seed=1, early_exit=True)
+    assert o["solved_fraction"] == 1.0 and o["solved"].cpu().numpy().all()
+    # a batch of different formulas is refused
+    from diffusionsat_amd import _lib
+    mixed = rt.Session(rt.Graph(make_batch([(n, clauses), _easy_formula(seed=4)])), w, max_rounds=R)
+    with pytest.raises(_lib.DsatError):
+        mixed.set_retire(True)
+
+
+def test_samples_with_retirement_gives_the_same_dictionary(rt, tmp_path):
+    """DiffusionSampler(..., retire_solved=True).samples(n) == the non-retiring sampler, on a formula with few
+    models (x1 & (x2|x3) & -x4: most copies fail, some are solved at different steps) and on a tautology."""
+    from diffusionsat_amd import weights as W
+    from diffusionsat_amd.diffusion_sampler import DiffusionSampler
+    from diffusionsat_amd.dimacs import DimacsFile
+    npz = tmp_path / "w.npz"
+    W.save_npz(str(npz), oracle_weights(5))
+    for name, clauses in (("few", [[1], [2, 3], [-4]]), ("taut", [[1, -1], [2, -2, 3], [-3, 3], [4, -4]])):
+        cnf = tmp_path / (name + ".cnf")
+        DimacsFile(str(cnf), clauses=clauses).store()
+        a = DiffusionSampler(str(npz), str(cnf), copies_per_batch=300)
+        b = DiffusionSampler(str(npz), str(cnf), copies_per_batch=300, retire_solved=True)
+        c = DiffusionSampler(str(npz), str(cnf), copies_per_batch=300, retire_solved=True)
+        c.host_recheck = True
+        ra, rb, rc = a.samples(200), b.samples(200), c.samples(200)
+        assert sum(ra.values()) == 200
+        assert ra == rb == rc, name
+        assert a.success_rate == b.success_rate
