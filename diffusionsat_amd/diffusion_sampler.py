@@ -122,6 +122,8 @@ class DiffusionSampler:
         # denoising steps run on fewer copies; results per copy as without it, except that the batch-global
         # early exit then refers to the copies still in the batch
         self.retire_solved = bool(retire_solved)
+        # is_batch_sat break inside every denoising step (model/query_sat.py:330-338), as in the reference
+        self.early_exit = True
         self._inputs: Dict[int, GraphInputs] = {}     # copies -> device graph
         self._slots: Dict[int, list] = {}             # copies -> [(session, stream), ...]
 
@@ -200,7 +202,7 @@ class DiffusionSampler:
         sess, stream = self._slots_for(k, copies)[it % k]
         stream.wait_stream(torch.cuda.current_stream(self.model.device))
         with torch.cuda.stream(stream):
-            out = sess.sample(diffusion_steps, test_rounds, seed=seed, early_exit=True,
+            out = sess.sample(diffusion_steps, test_rounds, seed=seed, early_exit=self.early_exit,
                               want_solved_fraction=False, self_conditioning=self_supervised)
             out["packed"] = sess.pack_assignment(out["assignment"])       # copies * ceil(n/8) bytes cross PCIe
         return stream, out

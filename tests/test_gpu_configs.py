@@ -300,6 +300,11 @@ def test_samples_with_retirement_gives_the_same_dictionary(rt, tmp_path):
         b = DiffusionSampler(str(npz), str(cnf), copies_per_batch=300, retire_solved=True)
         c = DiffusionSampler(str(npz), str(cnf), copies_per_batch=300, retire_solved=True)
         c.host_recheck = True
+        # the batch-global early exit is the one documented difference (with retirement it refers to the
+        # copies still in the batch, and two or three stubborn copies are easily all satisfied by chance
+        # in some round): switched off for the comparison
+        for smp in (a, b, c):
+            smp.early_exit = False
         ra, rb, rc = a.samples(200), b.samples(200), c.samples(200)
         assert sum(ra.values()) == 200
         assert ra == rb == rc, name
