@@ -38,7 +38,7 @@ class StreamSampler:
 
     def __init__(self, weights: runtime.Weights, device=None, slots: int = 2, n_steps: int = 32, rounds: int = 32,
                  seed: int = 0, pooled: bool = True, graph_replay: bool = True, early_exit: bool = True,
-                 arena_device_bytes: int = 96 << 20, arena_pinned_bytes: int = 8 << 20):
+                 arena_device_bytes: int = 256 << 20, arena_pinned_bytes: int = 16 << 20):
         self.weights = weights
         self.device = weights.device if device is None else runtime._device(device)
         self.n_steps, self.rounds, self.seed = int(n_steps), int(rounds), int(seed)
