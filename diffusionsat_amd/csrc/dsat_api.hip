@@ -825,11 +825,12 @@ static bool plan_round(dsat_session* s) {
     a.vgseg2 = s->n_vchunks > 0 ? s->vgseg2 : nullptr; a.psum2_v = s->psum2_v;
     a.cgseg2 = s->n_cchunks > 0 ? s->cgseg2 : nullptr; a.psum2_c = s->psum2_c;
     a.sel_tab = s->sel_tab; a.n_sel = s->n_sel; a.sel_zero = s->sel_zero;
+    a.sel_lead = s->sel_zero ? round_up(s->n_sel, 8) : 0;   // long select parts (a large graph) go first
     a.V = s->V; a.Cs = s->Cs; a.q = s->q; a.sp = s->sp; a.lits = s->lits; a.closs4 = s->closs4;
     a.vla = s->vla; a.ncv = s->ncv; a.newv = s->newv; a.logits = s->logits;
     a.psum_v = s->psum_v; a.psum_c_rd = s->psum_c; a.psum_c_wr = s->psum_c; a.noisy = s->in_noisy; a.ctl = s->ctl;
     a.aux = s->aux;
-    const int LDS = 40960;
+    const int LDS = ROUND_LDS_FLOATS;
     bool ok = true;
     {   // P1: [X 16x152 | Vlog 16x136 | A | B | mean]
         RoundArgs& r = s->ra1;
@@ -841,8 +842,13 @@ static bool plan_round(dsat_session* s) {
         r.ld_x = F + AUX_W + 8;
         r.ld_a = r.ld_b = hid + 8;
         r.off_x = 0;
+        // the pre-mix state tile (input of variables_output) lives only while the output / query pair runs,
+        // when the hidden buffers hold at most 160 columns: it borrows columns 256.. of buffer A's rows
+        const bool vlog_in_a = max_hidden_pad(w->mlp[DSAT_MLP_VARIABLES_OUTPUT]) + 8 <= 256 && r.ld_a >= 256 + F + 8;
         r.off_vlog = ROUND_BM_VAR * r.ld_x;
-        r.off_a = r.off_vlog + ROUND_BM_VAR * (F + 8);
+        r.off_a = vlog_in_a ? r.off_vlog : r.off_vlog + ROUND_BM_VAR * (F + 8);
+        r.ld_v = vlog_in_a ? r.ld_a : F + 8;
+        if (vlog_in_a) r.off_vlog = r.off_a + 256;
         r.off_b = r.off_a + ROUND_BM_VAR * r.ld_a;
         r.off_mean = r.off_b + ROUND_BM_VAR * r.ld_b;
         const int mean_floats = (ROUND_NWAVES * 64 / F + 1) * F;   // per-graph mean + one partial per thread group
@@ -929,7 +935,7 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         const int hid = max_hidden_pad(cl);
         int rb = 4;
         for (; rb > 1; rb >>= 1)
-            if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64 <= 40960) break;
+            if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64 <= ROUND_LDS_FLOATS) break;
         s->p2_rb = rb;
         build_segments(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg);
         build_segments(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg);

@@ -235,6 +235,7 @@ struct RoundArgs {
     const int32_t* sel_tab;
     int n_sel;
     int sel_zero;          // P3: zero graph_unsat (some graph has several select parts)
+    int sel_lead;          // P2: > 0 = the select/SAT workgroups occupy the first sel_lead blocks (multiple of 8)
     // debug taps (dsat_session_set_tap; nullptr in every production launch): values that only exist in
     // LDS on the fused path, written out by the tile that owns them
     float* tap_cmsg;       // P2: clause_messages [C,128]                       (query_sat.py:255-256)
@@ -244,7 +245,7 @@ struct RoundArgs {
     ChainSpec mq, mlit, mcl, mupd, mout;
     ChainSpec mq4, mout4;  // variables_query / variables_output blocked for 64-row tiles (P1 role B)
     // LDS plan (float offsets / row strides), filled by plan_round_lds
-    int ld_x, ld_a, ld_b, off_x, off_a, off_b, off_vlog, off_mean;
+    int ld_x, ld_a, ld_b, ld_v, off_x, off_a, off_b, off_vlog, off_mean;   // ld_v: row stride of the pre-mix state tile
 };
 constexpr int TILE_META_INTS = 16;
 constexpr int ROUND_BM_VAR = 16;    // rows per variable-side tile
@@ -258,7 +259,15 @@ constexpr int ROUND_BM_VAR = 16;    // rows per variable-side tile
 #endif
 constexpr int ROUND_NWAVES = DSAT_ROUND_NWAVES;
 static_assert(ROUND_NWAVES == 8 || ROUND_NWAVES == 16, "round kernels are written for 8 or 16 waves");
-constexpr int ROUND_TPW_CAP = ROUND_NWAVES >= 16 ? 2 : 8;   // tiles per wave the round kernels are built for
+// LDS of one round-kernel workgroup, in floats: all 160 KiB of the CU (one workgroup per CU), or, for the
+// two-workgroups-per-CU experiment (-DDSAT_ROUND_NWAVES=8 -DDSAT_ROUND_LDS_FLOATS=20480), half of it
+#ifndef DSAT_ROUND_LDS_FLOATS
+#define DSAT_ROUND_LDS_FLOATS 40960
+#endif
+constexpr int ROUND_LDS_FLOATS = DSAT_ROUND_LDS_FLOATS;
+constexpr int ROUND_WGS_PER_CU = 40960 / ROUND_LDS_FLOATS;
+// tiles per wave the round kernels are built for (register budget: 128 VGPRs per lane at four waves per SIMD)
+constexpr int ROUND_TPW_CAP = ROUND_NWAVES >= 16 ? 2 : (ROUND_WGS_PER_CU > 1 ? 4 : 8);
 hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st);
 hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st);
 hipError_t launch_round_p3(const RoundArgs& a, hipStream_t st);

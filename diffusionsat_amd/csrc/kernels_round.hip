@@ -46,7 +46,7 @@ constexpr int NT = ROUND_NWAVES * 64;
 // and push a 1024-thread workgroup (128 VGPRs per lane) into scratch spills.  An empty asm on the row
 // index pins the address arithmetic to the epilogue.
 #define NO_HOIST(x) asm volatile("" : "+v"(x))
-constexpr int LDS_FLOATS = 40960;   // 160 KiB static (see kernels_chain.hip on dynamic LDS)
+constexpr int LDS_FLOATS = ROUND_LDS_FLOATS;   // static (see kernels_chain.hip on dynamic LDS)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -469,7 +469,7 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
 //   C  blocks after that: finish the clause PairNorm of the previous round (R10; depends on P2(r-1)
 //      only), off P2's critical path.
 // The carried state is double-buffered by round (V_in -> V_out): A and B both read the old state.
-__global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
+__global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     constexpr int BM = ROUND_BM_VAR;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
         DSAT_STAMP_RT_END(a);
         return;
     }
-    const int ldx = a.ld_x, ldv = F + 8;
+    const int ldx = a.ld_x;
     float* lg = a.logits;
     float* tr = a.trace_logits != nullptr && a.round > 0
                     ? a.trace_logits + (size_t)(a.round - 1) * N * LOGIT_MAPS : nullptr;
@@ -504,6 +504,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
         float* sA = smem + a.b_off_a;
         float* sB = smem + a.b_off_b;
         float* sMean = smem + a.b_off_mean;
+        const int ldv = F + 8;
         DSAT_STAMP_RT_BEGIN(a);
         DSAT_STAMP(a, 0);
         if (tid < BM4) {
@@ -552,6 +553,7 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
     float* sB = smem + a.off_b;
     float* sMean = smem + a.off_mean;
     const bool pair_here = a.pair_blocks == 0;   // no role B in this launch: the tile runs the pair itself
+    const int ldv = a.ld_v;
 
     DSAT_STAMP_RT_BEGIN(a);
     DSAT_STAMP(a, 0);
@@ -619,22 +621,30 @@ __global__ __launch_bounds__(NT) void round_p1_kernel(RoundArgs a) {
 // select/SAT step of the PREVIOUS round for one graph each, on CUs the tiles leave idle:
 // it only feeds the early-exit flag and the step outputs, so it needs no launch of its own.
 template <int RB>
-__global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
+__global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     constexpr int BM = 16 * RB;
     constexpr int ROWS = (BM + NT / 32 - 1) / (NT / 32);   // clause rows per half-wave
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int C = a.C, NL = a.NL;
     const int tiles = (C + BM - 1) / BM;
-    const bool extra = (int)blockIdx.x >= tiles;
-    const int tile = extra ? 0 : xcd_tile(blockIdx.x, tiles);
+    // select/SAT workgroups normally follow the tiles (idle CUs pick them up); when a large graph makes them
+    // long (sel_lead > 0: its select is cut into parts that each take longer than a tile) they come FIRST,
+    // so they run beside the first wave of tiles instead of after the last.  sel_lead is a multiple of 8:
+    // the tiles keep their XCD mapping.
+    const int lead = a.s_enable ? a.sel_lead : 0;
+    const int tb = (int)blockIdx.x - lead;
+    if (tb < 0 && (int)blockIdx.x >= a.n_sel) return;
+    const bool extra = tb < 0 || tb >= tiles;
+    const int sel_blk = tb < 0 ? (int)blockIdx.x : tb - tiles;
+    const int tile = extra ? 0 : xcd_tile(tb, tiles);
     const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
     const TileMetaDev tm = load_meta(a.cmeta, tile);
     if (both_arrived(done, tm) != 0) return;
     if (extra) {
         DSAT_STAMP_RT_BEGIN(a);
         DSAT_STAMP(a, 0);
-        select_sat_body<NT>(blockIdx.x - tiles, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
+        select_sat_body<NT>(sel_blk, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
                             a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, NL, a.round - 1, a.check_done,
                             smem);
         DSAT_STAMP(a, 4);
@@ -773,7 +783,7 @@ __global__ __launch_bounds__(NT) void round_p2_kernel(RoundArgs a) {
 }
 
 // ------------------------------------------------------------------------------------- P3
-__global__ __launch_bounds__(NT) void round_p3_kernel(RoundArgs a) {
+__global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     constexpr int BM = ROUND_BM_VAR;
     constexpr int PASSES = BM / ROUND_NWAVES;   // variables per wave
@@ -1079,13 +1089,14 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
             label = (int)(philox4x32_10(c, (uint32_t)ctl->seed, (uint32_t)(ctl->seed >> 32)).x & 1u);
         }
         const float a = (float)label * (1.f - tl) + tl * 0.5f;
+        const float log_a = logf(a), log_1ma = log1pf(-a);     // bern_kl(a, b) with the b-free logs taken once
         const float4 l0 = ld4(logits + (size_t)v * LOGIT_MAPS);
         const float4 l1 = ld4(logits + (size_t)v * LOGIT_MAPS + 4);
         const float lg[LOGIT_MAPS] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
 #pragma unroll
         for (int k = 0; k < LOGIT_MAPS; ++k) {
             const float b = sigmoid_f(lg[k]) * (1.f - t) + t * 0.5f;
-            acc[k] += bern_kl(a, b) / norm;
+            acc[k] += (a * (log_a - logf(b)) + (1.f - a) * (log_1ma - log1pf(-b))) / norm;
         }
     }
 #pragma unroll
@@ -1188,7 +1199,7 @@ hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st) {
 }
 hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {
     const int bm = 16 * rb;
-    const int tiles = (a.C + bm - 1) / bm + (a.s_enable ? a.n_sel : 0);
+    const int tiles = (a.C + bm - 1) / bm + (a.s_enable ? (a.sel_lead > 0 ? a.sel_lead : a.n_sel) : 0);
     if (tiles == 0) return hipSuccess;
     if (rb == 4) hipLaunchKernelGGL(round_p2_kernel<4>, dim3(tiles), dim3(NT), 0, st, a);
     else if (rb == 2) hipLaunchKernelGGL(round_p2_kernel<2>, dim3(tiles), dim3(NT), 0, st, a);
