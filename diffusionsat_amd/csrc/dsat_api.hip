@@ -316,6 +316,7 @@ static int graph_create_impl(dsat_arena* arena, hipStream_t st, const int32_t* c
     g->h_c_rowptr.assign(clause_rowptr, clause_rowptr + C + 1);
     g->h_l_rowptr = l_rowptr;
     g->h_l_clause = l_clause;
+    g->h_c_lit = c_lit;
     {   // replicate batch? every graph the same formula up to the variable offset (early retirement needs it)
         bool same = G >= 1 && N % G == 0 && C % G == 0;
         const int np = same ? N / G : 0, mp = same ? C / G : 0;
@@ -613,6 +614,11 @@ struct dsat_session {
     std::vector<int32_t> h_lrp_light, h_lcl_light, h_lhv, h_pieces;   // lhv / pieces: int2 pairs, flattened
     int32_t *lrp_light = nullptr, *lcl_light = nullptr, *lhv = nullptr, *pieces = nullptr;
     float* hpart = nullptr;
+    // heavy clauses, the same on the clause side
+    int n_cpieces = 0;
+    std::vector<int32_t> h_crp_light, h_ccl_light, h_chv, h_cpieces;
+    int32_t *crp_light = nullptr, *ccl_light = nullptr, *chv = nullptr, *cpieces = nullptr;
+    float* chpart = nullptr;
     // level-2 PairNorm sums of graphs spread over many tiles (segsum2_kernel); empty unless needed
     std::vector<int32_t> h_vgseg2, h_vchunks, h_cgseg2, h_cchunks;    // chunks: int2 pairs, flattened
     int32_t *vgseg2 = nullptr, *vchunks = nullptr, *cgseg2 = nullptr, *cchunks = nullptr;
@@ -687,6 +693,13 @@ static void carve(dsat_session* s, Slab& sl) {
         s->lhv = sl.take<int32_t>(s->h_lhv.size());
         s->pieces = sl.take<int32_t>(s->h_pieces.size());
         s->hpart = sl.take<float>((size_t)s->n_pieces * 2 * F);
+    }
+    if (s->n_cpieces > 0) {
+        s->crp_light = sl.take<int32_t>(s->h_crp_light.size());
+        s->ccl_light = sl.take<int32_t>(std::max<size_t>(s->h_ccl_light.size(), 1));
+        s->chv = sl.take<int32_t>(s->h_chv.size());
+        s->cpieces = sl.take<int32_t>(s->h_cpieces.size());
+        s->chpart = sl.take<float>((size_t)s->n_cpieces * 2 * F);
     }
     if (s->n_vchunks > 0) {
         s->vgseg2 = sl.take<int32_t>(s->h_vgseg2.size());
@@ -822,6 +835,10 @@ static bool plan_round(dsat_session* s) {
     a.assign = s->assign;
     a.N = g->N; a.C = g->C; a.G = g->G;
     a.NL = g->N; a.CL = g->C;
+    a.cg_rowptr = s->n_cpieces > 0 ? s->crp_light : g->c_rowptr;
+    a.cg_lit = s->n_cpieces > 0 ? s->ccl_light : g->c_lit;
+    a.c_hv = s->n_cpieces > 0 ? reinterpret_cast<const int2*>(s->chv) : nullptr;
+    a.chpart = s->chpart;
     a.vgseg2 = s->n_vchunks > 0 ? s->vgseg2 : nullptr; a.psum2_v = s->psum2_v;
     a.cgseg2 = s->n_cchunks > 0 ? s->cgseg2 : nullptr; a.psum2_c = s->psum2_c;
     a.sel_tab = s->sel_tab; a.n_sel = s->n_sel; a.sel_zero = s->sel_zero;
@@ -1006,8 +1023,32 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             std::vector<int32_t> none((size_t)(g->N + 63) / 64 + 1, 0), zero_rp(2 * (size_t)g->N + 1, 0);
             build_tile_meta(g->h_var_seg, g->N, 64, none, s->h_vgseg, zero_rp.data(), -1, s->h_vmeta4);
         }
-        build_tile_meta(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg, g->h_c_rowptr.data(), -1,
-                        s->h_cmeta);
+        const int32_t* crp = g->h_c_rowptr.data();
+        if (g->max_clause_len > s->heavy_t) {   // heavy clauses: the mirror image of the heavy literal rows
+            s->h_crp_light.assign((size_t)g->C + 1, 0);
+            s->h_chv.assign(2 * (size_t)g->C, 0);
+            for (int c = 0; c < g->C; ++c) {
+                const int len = crp[c + 1] - crp[c];
+                if (len > s->heavy_t) {
+                    const int np = (len + HEAVY_PIECE - 1) / HEAVY_PIECE;
+                    s->h_chv[2 * (size_t)c] = (int32_t)(s->h_cpieces.size() / 2);
+                    s->h_chv[2 * (size_t)c + 1] = np;
+                    const int per = (len + np - 1) / np;
+                    for (int p = 0; p < np; ++p) {
+                        s->h_cpieces.push_back(crp[c] + p * per);
+                        s->h_cpieces.push_back(std::min(crp[c] + (p + 1) * per, crp[c + 1]));
+                    }
+                    s->h_crp_light[c + 1] = s->h_crp_light[c];
+                } else {
+                    s->h_chv[2 * (size_t)c] = -1;
+                    s->h_ccl_light.insert(s->h_ccl_light.end(), g->h_c_lit.begin() + crp[c], g->h_c_lit.begin() + crp[c + 1]);
+                    s->h_crp_light[c + 1] = s->h_crp_light[c] + len;
+                }
+            }
+            s->n_cpieces = (int)(s->h_cpieces.size() / 2);
+            crp = s->h_crp_light.data();
+        }
+        build_tile_meta(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg, crp, -1, s->h_cmeta);
     }
     Slab dry;
     carve(s.get(), dry);
@@ -1022,7 +1063,8 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
                                    s->h_lrp_light.size() + s->h_lcl_light.size() + s->h_lhv.size() +
                                    s->h_pieces.size() + s->h_vgseg2.size() + s->h_vchunks.size() +
                                    s->h_cgseg2.size() + s->h_cchunks.size() + s->h_sel_tab.size() + s->h_vmeta4.size() +
-                                   s->h_pack_off.size()) * sizeof(int32_t) + 24 * 64;
+                                   s->h_pack_off.size() + s->h_crp_light.size() + s->h_ccl_light.size() +
+                                   s->h_chv.size() + s->h_cpieces.size()) * sizeof(int32_t) + 32 * 64;
         char* stage = static_cast<char*>(arena->take_pin(meta_bytes));
         if (s->slab == nullptr || stage == nullptr) return arena_full(arena, "dsat_session_create_in");
         e = hipMemsetAsync(s->slab, 0, s->slab_bytes, st);
@@ -1047,6 +1089,12 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             if (e2 == hipSuccess) e2 = cp(s->lcl_light, s->h_lcl_light);
             if (e2 == hipSuccess) e2 = cp(s->lhv, s->h_lhv);
             if (e2 == hipSuccess) e2 = cp(s->pieces, s->h_pieces);
+        }
+        if (e2 == hipSuccess && s->n_cpieces > 0) {
+            e2 = cp(s->crp_light, s->h_crp_light);
+            if (e2 == hipSuccess) e2 = cp(s->ccl_light, s->h_ccl_light);
+            if (e2 == hipSuccess) e2 = cp(s->chv, s->h_chv);
+            if (e2 == hipSuccess) e2 = cp(s->cpieces, s->h_cpieces);
         }
         if (e2 == hipSuccess && s->n_vchunks > 0) {
             e2 = cp(s->vgseg2, s->h_vgseg2);
@@ -1087,6 +1135,12 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             if (e2 == hipSuccess) e2 = cp(s->lcl_light, s->h_lcl_light);
             if (e2 == hipSuccess) e2 = cp(s->lhv, s->h_lhv);
             if (e2 == hipSuccess) e2 = cp(s->pieces, s->h_pieces);
+        }
+        if (e2 == hipSuccess && s->n_cpieces > 0) {
+            e2 = cp(s->crp_light, s->h_crp_light);
+            if (e2 == hipSuccess) e2 = cp(s->ccl_light, s->h_ccl_light);
+            if (e2 == hipSuccess) e2 = cp(s->chv, s->h_chv);
+            if (e2 == hipSuccess) e2 = cp(s->cpieces, s->h_cpieces);
         }
         if (e2 == hipSuccess && s->n_vchunks > 0) {
             e2 = cp(s->vgseg2, s->h_vgseg2);
@@ -1486,6 +1540,11 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         a2.tap_cmsg = tapped ? tap->clause_messages : nullptr;
         a3.tap_grad = tapped ? tap->variables_grad : nullptr;
         a3.tap_vloss = tapped ? tap->variables_loss : nullptr;
+        if (s->n_cpieces > 0)   // sums of the heavy clauses, spread over the chip (reads P1's sp / lits)
+            L.run(KC_HEAVY, [&] {
+                note(launch_heavy_gather(reinterpret_cast<const int2*>(s->cpieces), s->n_cpieces, s->g->c_lit, s->sp,
+                                         s->lits, 2 * s->g->N, s->chpart, done_flag, st));
+            });
         L.run(KC_ROUND_P2, [&] { note(launch_round_p2(a2, s->p2_rb, st)); });
         if (s->n_cchunks > 0)   // level-2 sums of the clause column sums P2 just wrote (large graphs)
             L.run(KC_SEGSUM2, [&] {

@@ -86,6 +86,7 @@ struct dsat_graph {
     std::vector<int32_t> h_var_seg, h_cl_seg;
     std::vector<int32_t> h_c_rowptr, h_l_rowptr;   // host copies for the per-tile records
     std::vector<int32_t> h_l_clause;               // host copy of the literal->clause lists (heavy-row split)
+    std::vector<int32_t> h_c_lit;                  // host copy of the clause->literal lists (heavy-clause split)
     bool identical_copies = false;                 // every graph is the same formula (replicate batch)
 };
 
@@ -227,6 +228,13 @@ struct RoundArgs {
     // heavy_gather_kernel left in hpart ([piece][closs4 | vla][128]) in piece order.
     const int2* l_hv;      // [2N] {first piece, pieces} or {-1, 0}; nullptr when the batch has no heavy row
     const float* hpart;
+    // Heavy clauses (more than HEAVY_ROW_T literals), the same way on the clause side: P2's gather walks
+    // cg_rowptr / cg_lit (the clause->literal CSR with those rows emptied; = c_rowptr / c_lit when there are
+    // none) and adds the pieces in chpart ([piece][softplus sum | literal sum][128]); select/SAT keeps the
+    // full CSR in c_rowptr / c_lit.
+    const int32_t *cg_rowptr, *cg_lit;
+    const int2* c_hv;      // [C] {first piece, pieces}; nullptr when the batch has no heavy clause
+    const float* chpart;
     // Graphs spread over more than SEG2_MIN tiles: their per-tile column sums are pre-summed in chunks
     // (segsum2_kernel); [gseg2[g], gseg2[g+1]) is the graph's range in psum2 (empty for other graphs).
     const int32_t *vgseg2, *cgseg2;   // nullptr when the batch has no such graph

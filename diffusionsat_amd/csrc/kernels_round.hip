@@ -664,7 +664,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
     // the clause rows' literal lists -> LDS (sA is free until the first layer writes it)
     int* sPtr = reinterpret_cast<int*>(sA);
     int* sIdx = sPtr + BM + 8;
-    const bool staged = stage_csr(a.c_rowptr, a.c_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr,
+    const bool staged = stage_csr(a.cg_rowptr, a.cg_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr,
                                   sIdx, BM * a.ld_a - (BM + 8), tid);
     if (a.cs_ready && a.round > 0) {   // R10 was finished by P1's extra blocks: just load the rows
         const int sub = tid & 31, hw = tid >> 5;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
             rwv[u] = tile_lo + r < tile_hi ? a.rev_w[tile_lo + r] : 0.f;
             if (tile_lo + r < tile_hi) {
                 if (staged) { e0[u] = sPtr[r]; e1[u] = sPtr[r + 1]; }
-                else { e0[u] = a.c_rowptr[tile_lo + r]; e1[u] = a.c_rowptr[tile_lo + r + 1]; }
+                else { e0[u] = a.cg_rowptr[tile_lo + r]; e1[u] = a.cg_rowptr[tile_lo + r + 1]; }
             }
             nmax = max(nmax, e1[u] - e0[u]);
         }
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
                     const bool ok = e < e1[u];
                     int idx;
                     if (staged) idx = sIdx[e];
-                    else idx = ok ? a.c_lit[e] : 0;
+                    else idx = ok ? a.cg_lit[e] : 0;
                     l[u][j] = ok ? (unsigned)idx : zrow;
                 }
 #pragma unroll
@@ -738,6 +738,21 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
                     S[u].x += sv[u][j].x; S[u].y += sv[u][j].y; S[u].z += sv[u][j].z; S[u].w += sv[u][j].w;
                     M[u].x += lv[u][j].x; M[u].y += lv[u][j].y; M[u].z += lv[u][j].z; M[u].w += lv[u][j].w;
                 }
+        }
+        if (a.c_hv != nullptr) {   // heavy clauses: their sums come in pieces from heavy_gather_kernel
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = tile_lo + hw + u * (NT / 32);
+                if (c < tile_hi) {
+                    const int2 hv = a.c_hv[c];
+                    for (int p = 0; p < hv.y; ++p) {
+                        const float* hp = a.chpart + ((size_t)(hv.x + p) * 2) * F + sub * 4;
+                        const float4 s4 = ld4(hp), m4 = ld4(hp + F);
+                        S[u].x += s4.x; S[u].y += s4.y; S[u].z += s4.z; S[u].w += s4.w;
+                        M[u].x += m4.x; M[u].y += m4.y; M[u].z += m4.z; M[u].w += m4.w;
+                    }
+                }
+            }
         }
         // the last part of the tile preparation runs inside the chain, after it has asked for
         // its first weight fragments (run_chain's `prep`), and the chain takes the barrier
@@ -996,6 +1011,8 @@ __global__ __launch_bounds__(1024) void segsum2_kernel(const int2* __restrict__ 
 // One workgroup (8 half-waves) per piece of a heavy literal row: half-wave h sums entries
 // [e_lo + h*per, e_lo + (h+1)*per) of the piece (closs4 and vla rows of those clauses, in list
 // order), the eight sums are combined in half-wave order: deterministic, no atomics.
+// (The same kernel serves heavy CLAUSES before P2: idx = the clause's literal rows, the arrays sp / lits,
+// the zero row 2*N.)
 __global__ __launch_bounds__(256) void heavy_gather_kernel(const int2* __restrict__ pieces,
                                                            const int32_t* __restrict__ l_clause,
                                                            const float* __restrict__ closs4,

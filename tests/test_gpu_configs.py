@@ -309,3 +309,37 @@ def test_samples_with_retirement_gives_the_same_dictionary(rt, tmp_path):
         assert sum(ra.values()) == 200
         assert ra == rb == rc, name
         assert a.success_rate == b.success_rate
+
+
+def test_very_long_clauses_match_oracle(rt):
+    """Clauses far longer than anything 3-SAT has: one of 700 literals and one of 5 000 (beyond the LDS
+    staging area of a clause tile, so the unstaged gather path runs) among ordinary ones, variables that sit in
+    both; 6 rounds of per-round logits and the clause-side taps against the oracle."""
+    from diffusionsat_amd.batch import make_batch
+    rng = np.random.default_rng(12)
+    n = 6000
+    clauses = [[int(v + 1) if rng.random() < 0.5 else -int(v + 1) for v in rng.choice(n, size=3, replace=False)]
+               for _ in range(3000)]
+    for L in (700, 5000):
+        vs = rng.choice(n, size=L, replace=False)
+        clauses.insert(int(rng.integers(0, len(clauses))),
+                       [int(v + 1) if rng.random() < 0.5 else -int(v + 1) for v in vs])
+    small = (40, [[1, -2, 3], [4, 5], [-6, 7, 8, 9]])
+    insts = [small, (n, clauses)]
+    batch = make_batch(insts)
+    data = O.create_adj_matrices(insts)
+    ws = oracle_weights(8)
+    rounds = 6
+    d = draws(batch.n_vars, rounds, seed=4)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.45), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32, trace=("logits", "clause_messages", "clauses_loss4"))
+    s = rt.Session(rt.Graph(batch), rt.Weights(ws), max_rounds=rounds)
+    out = s.diffusion_step(0.45, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds, early_exit=False,
+                           want_round_logits=True, tap_round=1)
+    got = out["round_logits"].cpu().numpy()
+    for r in range(rounds):
+        assert np.abs(got[r] - ref["trace"]["logits"][r]).max() < 5e-4, r
+    for k in ("clause_messages", "clauses_loss4"):
+        a, b = out["tap"][k].cpu().numpy(), ref["trace"][k][1]
+        assert np.abs(a - b).max() < 1e-4 * max(1.0, float(np.abs(b).max())), k
