@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <numeric>
@@ -1473,6 +1474,36 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
     }
 }
 
+// How many 64-row groups P1's role B should cover.  One workgroup per CU, 256 CUs, workgroups start in block
+// order: with a single wave of workgroups (vtiles + groups <= 256) everything is co-resident and role B takes
+// all groups.  On larger grids a few workgroups too many cost a whole extra tile time at the end (625 + 157
+// workgroups = 3.05 waves), so the candidates are compared by a list-scheduling estimate with the measured
+// relative durations (profiles/r02_stamps_*: A tile without the pair 74, with it 95, role-B workgroup 72).
+static void plan_pair_blocks(int n_active, int* first, int* blocks) {
+    const int vtiles = (n_active + ROUND_BM_VAR - 1) / ROUND_BM_VAR, groups = (n_active + 63) / 64;
+    *first = 0;
+    *blocks = groups;
+    if (vtiles + groups <= 256) return;
+    auto makespan = [&](int nb) {
+        const int f = groups - nb;                    // rows below 64*f: pair in the A tile
+        std::vector<double> cu(256, 0.0);             // finish times; the next block goes to the earliest CU
+        std::make_heap(cu.begin(), cu.end(), std::greater<double>());
+        auto put = [&](double d) {
+            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+            cu.back() += d;
+            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+        };
+        for (int t = 0; t < vtiles; ++t) put(t * ROUND_BM_VAR < f * 64 ? 95.0 : 74.0);
+        for (int b = 0; b < nb; ++b) put(72.0);
+        return *std::max_element(cu.begin(), cu.end());
+    };
+    double best = makespan(groups);
+    for (int nb = 0; nb < groups; nb += std::max(1, groups / 64)) {
+        const double m = makespan(nb);
+        if (m < best - 1e-9) { best = m; *blocks = nb; *first = groups - nb; }
+    }
+}
+
 // Fused launch sequence: per round P1 -> [S of the previous round] -> P2 -> P3, then the tail
 // P1 (last round's PairNorm + logits) and the last S.
 static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int early_exit, float* trace_logits,
@@ -1495,6 +1526,7 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
     }
     a1.check_done = a2.check_done = a3.check_done = early_exit;
     a1.trace_logits = trace_logits;
+    int pb_first = 0, pb_blocks = -1;
     // the non-state columns of v1 (normal draw, noisy_num, noise_scale, denoised) of all rounds
     L.run(KC_MISC, [&] { launch_aux(s->aux, actN, rounds, s->in_noisy, s->ctl, st); });   // :214-219, :239
     for (int r = 0; r <= rounds; ++r) {
@@ -1507,7 +1539,13 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         const int vtiles = (actN + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
         // role B (output / query pair on 64-row tiles) in every launch but the tail, which is the pair's
         // output half alone
-        a1.pair_blocks = (a1.tail || s->pair_blocks == 0) ? 0 : (actN + 63) / 64;
+        a1.pair_blocks = 0;
+        a1.pair_first = 0;
+        if (!a1.tail && s->pair_blocks != 0) {
+            if (r == 0 || pb_blocks < 0) plan_pair_blocks(actN, &pb_first, &pb_blocks);
+            a1.pair_blocks = pb_blocks;
+            a1.pair_first = pb_first;
+        }
         const int free_cus = 256 - vtiles - a1.pair_blocks;
         const int cn = (r > 0 && r < rounds && actC > 0 && free_cus >= 8 && !s->no_cn) ? free_cus : 0;
         a1.cn_blocks = cn;

@@ -214,6 +214,7 @@ struct RoundArgs {
     // P1 role B (kernels_round.hip): 64-row tiles running the output / query pair on otherwise idle CUs
     const int32_t* vmeta4;   // per 64-row tile records
     int pair_blocks;         // 0 = the 16-row tiles run the pair themselves
+    int pair_first;          // first 64-row group role B covers (rows below it: the pair runs in the 16-row tile)
     int b_off_x, b_off_vlog, b_off_a, b_off_b, b_off_mean, b_ld_a, b_ld_b;   // LDS plan of a role-B workgroup
     int s_enable;          // P2 only: append G blocks running select/SAT of round-1
     int cn_blocks;         // P1 only: extra blocks that finish the clause PairNorm of round-1 (R10)

@@ -477,7 +477,10 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
     const int vtiles = (N + BM - 1) / BM;
     const int b = blockIdx.x;
     const bool roleA = b < vtiles, roleB = !roleA && b < vtiles + a.pair_blocks;
-    const int tile = roleA ? xcd_tile(b, vtiles) : (roleB ? b - vtiles : 0);
+    // role B covers the 64-row groups [pair_first, pair_first + pair_blocks): normally all of them; on grids of
+    // several waves of workgroups only as many as make the block count fit the waves (dsat_api.hip,
+    // plan_pair_blocks) -- the A tiles of the uncovered FIRST rows run the pair themselves and start first
+    const int tile = roleA ? xcd_tile(b, vtiles) : (roleB ? a.pair_first + (b - vtiles) : 0);
     // the early-exit flag and the tile record are requested together: one memory latency, not two
     const int done = a.check_done ? a.ctl->done : 0;
     const TileMetaDev tm = load_meta(roleB ? a.vmeta4 : a.vmeta, tile);
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
     float* sA = smem + a.off_a;
     float* sB = smem + a.off_b;
     float* sMean = smem + a.off_mean;
-    const bool pair_here = a.pair_blocks == 0;   // no role B in this launch: the tile runs the pair itself
+    const bool pair_here = a.pair_blocks == 0 || tile_lo < a.pair_first * 64;   // no role-B workgroup covers these rows
     const int ldv = a.ld_v;
 
     DSAT_STAMP_RT_BEGIN(a);
