@@ -373,3 +373,61 @@ def test_device_packed_assignment_bits(rt):
         va.assign_all_from_bit_list(bits[v0:v0 + n])
         assert int.from_bytes(chunk.tobytes(), "little") == int(va)          # the reference's int encoding
         v0 += n
+
+
+def test_hip_path_symmetries(rt):
+    """The exact symmetries of the path, on the HIP path itself (tests/test_oracle.py has them for the oracle):
+    renumbering the variables, reordering the clauses and shuffling the literals inside clauses -- what
+    the reference's invariance_shuffle_literals feeds the model (diffusion_training.py:455-463) -- leave
+    the per-variable logits unchanged up to summation order."""
+    from diffusionsat_amd.batch import make_batch
+    (n, clauses), = make_all("uf20")[0]
+    ws = oracle_weights(6)
+    rounds = 6
+    d = draws(n, rounds, seed=9)
+    noisy = O.randomized_rounding(np.full((n, 2), 0.5, dtype=np.float32), d["uniform"])
+
+    def run(cl, perm=None):
+        inv = np.arange(n) if perm is None else np.argsort(perm)
+        s = _session(rt, make_batch([(n, cl)]), ws, max_rounds=rounds)
+        out = s.diffusion_step(0.6, _dev(noisy[inv]), _dev(d["normal"][:, inv]), _dev(d["labels"][inv]), rounds=rounds,
+                               early_exit=False, want_logits=True)
+        return out["logits"].cpu().numpy()
+
+    base = run(clauses)
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(n)
+    pc = [[int(np.sign(l)) * int(perm[abs(l) - 1] + 1) for l in c] for c in clauses]
+    assert np.abs(run(pc, perm)[perm] - base).max() < 2e-5
+    order = rng.permutation(len(clauses))
+    sc = [[int(x) for x in rng.permutation(clauses[i])] for i in order]
+    assert np.abs(run(sc) - base).max() < 2e-5
+    # inverting every literal is not a symmetry of the network (see the oracle test): really different
+    assert np.abs(run([[-l for l in c] for c in clauses]) - base).max() > 1e-3
+
+
+def test_objects_are_bound_to_their_device(rt):
+    """Handles remember the HIP device they were created on; a call made with another device current is
+    refused (DSAT_E_STATE) instead of launching on the wrong GPU.  Needs two GPUs to provoke."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    import ctypes as C
+    from diffusionsat_amd import _lib
+    _, batch, _ = make_all("3sat")
+    g0 = rt.Graph(batch, device="cuda:0")
+    w1 = rt.Weights(oracle_weights(0), device="cuda:1")
+    with pytest.raises(ValueError):
+        rt.Session(g0, w1)
+    h = C.c_void_p()
+    with torch.cuda.device(0):
+        rc = _lib.load().dsat_session_create(g0.handle, w1.handle, 4, C.byref(h))
+    assert rc == -4 and b"device" in _lib.load().dsat_last_error()
+    s0 = rt.Session(g0, rt.Weights(oracle_weights(0), device="cuda:0"))
+    pred = torch.empty(batch.n_vars, device="cuda:0")
+    noisy = torch.zeros(batch.n_vars, 2, device="cuda:0")
+    with torch.cuda.device(1):      # the raw call with the wrong device current
+        rc = _lib.load().dsat_diffusion_step(s0.handle, 0.5, noisy.data_ptr(), None, None, 0, 0, 4, 0, None, None,
+                                              pred.data_ptr(), None, None, None)
+    assert rc == -4
+    out = s0.diffusion_step(0.5, noisy, rounds=4)            # the Python handle switches devices itself
+    assert out["prediction"].device.index == 0
