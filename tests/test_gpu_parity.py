@@ -431,3 +431,35 @@ def test_objects_are_bound_to_their_device(rt):
     assert rc == -4
     out = s0.diffusion_step(0.5, noisy, rounds=4)            # the Python handle switches devices itself
     assert out["prediction"].device.index == 0
+
+
+@pytest.mark.parametrize("hidden,layers", [((100, 300, 150, 200, 64), (2, 2, 2, 3, 2)),
+                                           ((153, 512, 204, 230, 128), (2, 4, 2, 2, 3)),
+                                           ((40, 64, 48, 72, 24), (3, 3, 3, 3, 2))])
+def test_other_layer_counts_and_hidden_widths(rt, hidden, layers):
+    """The reference constructor derives layer counts and hidden widths from its arguments
+    (model/query_sat.py:101-122: msg_layers, the *_scale factors).  Anything but the released shapes leaves
+    the compile-time-blocked chains and runs the generic per-layer weight-streaming path (and, for P1,
+    the in-tile output/query pair): 6 rounds of logits against the oracle for three such layouts."""
+    from diffusionsat_amd import _lib
+    _, batch, data = make_all("medium")
+    lay = _lib.default_layout()
+    for m in range(5):
+        lay.n_layers[m] = layers[m]
+        lay.hidden[m] = hidden[m]
+    v1 = 128 + 9
+    ins = (v1, v1, 384, 128 + v1 + 256, 128)
+    outs = (128, 256, 256, 128, 8)
+    dims = {name: [ins[m]] + [hidden[m]] * (layers[m] - 1) + [outs[m]] for m, name in enumerate(O.MLP_ORDER)}
+    ws = O.make_weights(13, np.float32, bias_scale=0.05, dims=dims)
+    rounds = 6
+    d = draws(batch.n_vars, rounds, seed=17)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, dtype=np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.5), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32, trace=("logits",))
+    s = rt.Session(rt.Graph(batch), rt.Weights(ws, lay), max_rounds=rounds)
+    out = s.diffusion_step(0.5, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds, early_exit=False,
+                           want_round_logits=True)
+    got = out["round_logits"].cpu().numpy()
+    for r in range(rounds):
+        _close(got[r], ref["trace"]["logits"][r], 0, LOGIT_TOL)
