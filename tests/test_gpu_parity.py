@@ -463,3 +463,76 @@ def test_other_layer_counts_and_hidden_widths(rt, hidden, layers):
     got = out["round_logits"].cpu().numpy()
     for r in range(rounds):
         _close(got[r], ref["trace"]["logits"][r], 0, LOGIT_TOL)
+
+
+import os
+
+
+def _fuzz_instances(seed):
+    """Random batch structure: many graphs of 1..70 variables (so a 16-row tile can span up to 16 graphs and a
+    64-row clause tile dozens), clause widths 1..7 with repeated and complementary literals, variables
+    that occur nowhere, graphs with a single clause."""
+    rng = np.random.default_rng(1000 + seed)
+    style = seed % 4
+    n_graphs = int(rng.integers(1, 60))
+    insts = []
+    for _ in range(n_graphs):
+        if style == 0:
+            n = int(rng.integers(1, 4))                 # tiny graphs only
+        elif style == 1:
+            n = int(rng.integers(1, 70))
+        elif style == 2:
+            n = int(rng.choice([1, 2, 16, 17, 31, 32, 33, 64, 65]))   # tile-boundary sizes
+        else:
+            n = int(rng.integers(1, 12)) if rng.random() < 0.8 else int(rng.integers(100, 300))
+        m = int(rng.integers(1, max(2, 5 * n)))
+        clauses = []
+        for _ in range(m):
+            k = int(rng.integers(1, 8))
+            lits = rng.integers(1, n + 1, k) * rng.choice([-1, 1], k)
+            clauses.append([int(x) for x in lits])
+        insts.append((n, clauses))
+    return insts
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_batch_structures_match_oracle(rt, seed):
+    """Structure fuzz (the reference batches whatever the dataset yields, data/k_sat.py:60-117: any mix of
+    sizes): 3 rounds of logits, the per-graph clause loss and the SAT flags against the oracle, on both
+    the fused and the per-layer path."""
+    insts = _fuzz_instances(seed)
+    from diffusionsat_amd.batch import make_batch
+    batch = make_batch(insts)
+    data = O.create_adj_matrices(insts)
+    ws = oracle_weights(seed)
+    rounds = 3
+    d = draws(batch.n_vars, rounds, seed=seed)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, dtype=np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.3), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32, trace=("logits",))
+    g = rt.Graph(batch)
+    w = rt.Weights(ws)
+    for fused in (1, 0):
+        os.environ["DSAT_FUSED"] = str(fused)
+        try:
+            s = rt.Session(g, w, max_rounds=rounds)
+            out = s.diffusion_step(0.3, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds,
+                                   early_exit=False, want_round_logits=True)
+        finally:
+            os.environ.pop("DSAT_FUSED", None)
+        got = out["round_logits"].cpu().numpy()
+        for r in range(rounds):
+            _close(got[r], ref["trace"]["logits"][r], 0, LOGIT_TOL)
+    # is_graph_sat on a random +-1 prediction: integer work, exact
+    pred = np.random.default_rng(seed).choice([-2.0, 2.0], batch.n_vars).astype(np.float32)
+    adj = data["adjacency_matrix"]
+    sat_ref = O.is_graph_sat(pred, adj, data["clauses_graph_adj"])
+    got = s.op_is_graph_sat(_dev(pred)).cpu().numpy()
+    assert np.array_equal(got.astype(np.int64), np.asarray(sat_ref).astype(np.int64))
+    bits = (pred > 0).astype(np.uint8)
+    packed = s.pack_assignment(_dev(bits)).cpu().numpy()
+    off = s.packed_offsets()
+    v0 = 0
+    for gi, (n, _) in enumerate(insts):
+        assert np.array_equal(packed[off[gi]:off[gi + 1]], np.packbits(bits[v0:v0 + n], bitorder="little"))
+        v0 += n
