@@ -14,6 +14,9 @@ shapes = {
     "irregular": [I.irregular_cnf(1500, 9000, seed=5, zipf_a=1.1)[:2], I.irregular_cnf(700, 3000, seed=6)[:2]],
     "mixed-ksat": [I.sr_ksat(seed=s, min_vars=20, max_vars=60) for s in range(12)],
     "tiny": [(3, [[1, -2], [2, 3]])],
+    # heavy literal rows and heavy clauses (split pieces + heavy_gather), level-2 PairNorm sums, select parts
+    "heavy": [I.irregular_cnf(9000, 40000, seed=7, zipf_a=1.1)[:2]],
+    "long-clauses": [(40, [[(i % 40 + 1) * (1 if (i * 7 + j) % 3 else -1) for i in range(j, j + 33 + 5 * j)] for j in range(12)])],
 }
 w = runtime.Weights(W.glorot_weights(0))
 t_end = time.time() + budget
