@@ -438,6 +438,28 @@ extern "C" int dsat_graph_info(const dsat_graph* g, int32_t* n_vars, int32_t* n_
 }
 
 // ============================================================================ weights
+// x = h + m + l with three bf16 values (round to nearest even at every step; the residuals are exact in
+// fp32): the slices the split-product kernels multiply (split_bf16.h has the device twin).
+static inline uint16_t bf16_rne_host(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_float_host(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline void split3_host(float x, uint16_t (&o)[3]) {
+    o[0] = bf16_rne_host(x);
+    const float r1 = x - bf16_to_float_host(o[0]);
+    o[1] = bf16_rne_host(r1);
+    const float r2 = r1 - bf16_to_float_host(o[1]);
+    o[2] = bf16_rne_host(r2);
+}
+
 // Pack one Dense layer: wt[npad][kpad] = kernel^T with each input block padded to a
 // multiple of 16 along K and N padded to a multiple of 32, zeros elsewhere.
 static void pack_layer(const float* kernel, const float* bias, int in_dim, int out_dim,
@@ -525,7 +547,13 @@ extern "C" int dsat_weights_load(const float* blob, int64_t n_floats, const dsat
         staged.push_back(std::move(s));
     }
     size_t total = 0;
-    for (auto& s : staged) total += 2 * ((s.wt.size() + 63) & ~size_t(63)) + ((s.bias.size() + 63) & ~size_t(63));
+    // per layer: wt, its fragment-ordered copy, bias, and the three bf16 slices (6 bytes per weight of the
+    // k-step-padded matrix, counted in floats)
+    auto split_floats = [](const PackedLayer& pl) {
+        return (((size_t)pl.ntiles() * pl.ksteps() * 3 * 64 * 8 / 2) + 63) & ~size_t(63);
+    };
+    for (auto& s : staged)
+        total += 2 * ((s.wt.size() + 63) & ~size_t(63)) + ((s.bias.size() + 63) & ~size_t(63)) + split_floats(*s.dst);
     w->slab_bytes = total * sizeof(float);
     DSAT_HIP(hipMalloc((void**)&w->slab, w->slab_bytes));
     size_t off = 0;
@@ -551,6 +579,26 @@ extern "C" int dsat_weights_load(const float* blob, int64_t n_floats, const dsat
             if (e == hipSuccess)
                 e = hipMemcpy(s.dst->wp, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice);
             off += (wp.size() + 63) & ~size_t(63);
+        }
+        {   // bf16 slices of the same weights (split_bf16.h)
+            const PackedLayer& pl = *s.dst;
+            const int ks = pl.ksteps(), nt = pl.ntiles();
+            std::vector<uint16_t> ws((size_t)nt * ks * 3 * 64 * 8, 0);
+            for (int t = 0; t < nt; ++t)
+                for (int st = 0; st < ks; ++st)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 32 * st + 8 * (l >> 4) + j;
+                            const float v = k < pl.kpad ? s.wt[(size_t)(t * 16 + (l & 15)) * pl.kpad + k] : 0.f;
+                            uint16_t h3[3];
+                            split3_host(v, h3);
+                            const size_t base = (((size_t)t * ks + st) * 3) * 64 * 8;
+                            for (int pnum = 0; pnum < 3; ++pnum) ws[base + ((size_t)pnum * 64 + l) * 8 + j] = h3[pnum];
+                        }
+            s.dst->ws = reinterpret_cast<uint16_t*>(w->slab + off);
+            if (e == hipSuccess)
+                e = hipMemcpy(s.dst->ws, ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+            off += split_floats(pl);
         }
         if (e != hipSuccess) {
             dsat_weights_destroy(w.release());
@@ -606,6 +654,7 @@ struct dsat_session {
     // fused round kernels (kernels_round.hip)
     int use_fused = 1;
     int p2_rb = 4;
+    int p2_split = 0;   // P2 runs round_p2s_kernel (fp32 products from bf16 slices)
     float *sp = nullptr, *psum_v = nullptr, *psum_c = nullptr;
     int32_t *vmeta = nullptr, *vgseg = nullptr, *cmeta = nullptr, *cgseg = nullptr;
     std::vector<int32_t> h_vtile_seg, h_vgseg, h_ctile_seg, h_cgseg, h_vmeta, h_cmeta;
@@ -909,6 +958,37 @@ static bool plan_round(dsat_session* s) {
         r.off_b = layers.size() > 2 ? r.off_a + bm * r.ld_a : r.off_a;
         r.off_mean = r.off_b + bm * r.ld_b;
         ok = ok && (r.off_mean + ROUND_NWAVES * 64 <= LDS);
+        // the split-product form of the tile (round_p2s_kernel): two layers, 64 rows, 16 waves, one column
+        // tile per wave; LDS = [buf1: one 128-column segment as three bf16 planes | buf2: the hidden tile's
+        // planes (first a segment, and fp32 scratch of the in-kernel PairNorm) + the staged CSR lists | sums]
+        s->p2_split = 0;
+        const char* sw = getenv("DSAT_P2_SPLIT");
+        if (rb == 4 && ROUND_NWAVES == 16 && layers.size() == 2 && layers[0].kpad == 3 * F &&
+            r.mcl.L[0].ntiles <= ROUND_NWAVES && r.mcl.L[1].ntiles <= ROUND_NWAVES &&
+            r.mcl.L[0].ntiles * 16 <= layers[1].ksteps() * 32 && !(sw != nullptr && sw[0] == '0')) {
+            const int ks1 = layers[1].ksteps();
+            r.s_ld_seg = F + 8;
+            r.s_ld_hid = ks1 * 32 + 8;
+            const int seg_bytes = 3 * bm * r.s_ld_seg * 2, hid_bytes = 3 * bm * r.s_ld_hid * 2;
+            const int scratch_bytes = (bm + ROUND_NWAVES * 64 / F) * (F + 8) * 4;   // PairNorm rows + partial sums
+            const int lists_at = std::max(seg_bytes, scratch_bytes);
+            const int buf2_bytes = std::max(hid_bytes, lists_at + 16 * 1024);
+            r.s_buf1 = 0;
+            r.s_buf2 = seg_bytes;
+            r.s_idx = r.s_buf2 + lists_at;
+            r.s_idx_cap = (buf2_bytes - lists_at) / 4 - (bm + 8);
+            r.s_mean = r.s_buf2 + buf2_bytes;
+            if (r.s_mean + ROUND_NWAVES * 64 * 4 <= LDS * 4 && (bm * (F + 8) + ROUND_NWAVES * 64) * 4 <= seg_bytes) {
+                r.cl_ws[0] = reinterpret_cast<const uint4*>(layers[0].ws);
+                r.cl_ws[1] = reinterpret_cast<const uint4*>(layers[1].ws);
+                r.cl_ks[0] = layers[0].ksteps(); r.cl_ks[1] = ks1;
+                r.cl_nt[0] = r.mcl.L[0].ntiles; r.cl_nt[1] = r.mcl.L[1].ntiles;
+                s->p2_split = 1;
+            }
+        }
+        if (getenv("DSAT_DEBUG_PLAN") != nullptr)
+            fprintf(stderr, "[dsat] P2 rb=%d split=%d (buf2 at %d, lists at %d cap %d, sums at %d of %d bytes)\n", rb,
+                    s->p2_split, r.s_buf2, r.s_idx, r.s_idx_cap, r.s_mean, LDS * 4);
     }
     {   // P3: [X 16x536 | A | B]
         RoundArgs& r = s->ra3;

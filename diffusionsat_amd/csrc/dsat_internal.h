@@ -41,6 +41,11 @@ struct PackedLayer {
     // [npad/16 tiles][kpad/16 k-blocks][64 lanes][4]; lane l, element j holds
     // W[k = 16*kb + 4*(l>>4) + j][n = 16*t + (l&15)]
     float* wp = nullptr;
+    // the same weights as three bf16 slices (w = h + m + l to 24 bits) for v_mfma_f32_16x16x32_bf16:
+    // [npad/16 tiles][ksteps of 32][3 planes][64 lanes][8]; lane l, element j holds
+    // slice(W[k = 32*s + 8*(l>>4) + j][n = 16*t + (l&15)]), zero beyond kpad (split_bf16.h)
+    uint16_t* ws = nullptr;
+    int ksteps() const { return (kpad + 31) / 32; }
     int ntiles() const { return npad / 16; }
     int kblocks() const { return kpad / 16; }
 };
@@ -253,6 +258,12 @@ struct RoundArgs {
     // weights
     ChainSpec mq, mlit, mcl, mupd, mout;
     ChainSpec mq4, mout4;  // variables_query / variables_output blocked for 64-row tiles (P1 role B)
+    // P2 with fp32 products formed from bf16 slices (round_p2s_kernel, split_bf16.h): per layer the weights as
+    // three bf16 planes in fragment order, k-steps of 32 and column tiles; LDS plan in BYTES / bf16 elements
+    const uint4* cl_ws[2];
+    int cl_ks[2], cl_nt[2];
+    int s_buf1, s_buf2, s_idx, s_idx_cap, s_mean;   // byte offsets (s_idx_cap: ints)
+    int s_ld_seg, s_ld_hid;                         // row strides of the plane images, bf16 elements
     // LDS plan (float offsets / row strides), filled by plan_round_lds
     int ld_x, ld_a, ld_b, ld_v, off_x, off_a, off_b, off_vlog, off_mean;   // ld_v: row stride of the pre-mix state tile
 };

@@ -17,6 +17,7 @@
 // the consumer adds a graph's segments in index order: deterministic, no atomics.
 #include "dsat_internal.h"
 #include "fused_common.h"
+#include "split_bf16.h"
 #include "philox.h"
 
 namespace dsat {
@@ -800,6 +801,260 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
     }
 }
 
+// ------------------------------------------------------------------------------------- P2, split products
+// The same clause tile with clause_mlp's products formed from bf16 slices (split_bf16.h): 2.5x fewer MFMA cycles
+// at fp32-level error.  64 rows, 16 waves.  The operands are 6 bytes per element, so the 64 x 384 input tile no
+// longer fits LDS as a whole: layer 0 takes its three 128-column segments [clause_state | messages | loss]
+// (query_sat.py:258) through two buffers,
+//     buf1: state (k-steps 0-3)  ->  loss (k-steps 8-11)          52 KiB
+//     buf2: messages (k-steps 4-7)  ->  layer 0's output planes    87 KiB (+ the staged CSR lists behind them)
+// with two extra barriers; the fp32 stage of the column sums reuses buf1.  Column tiles of layer 0: one per wave;
+// with 13 tiles (the released 204-wide layer) waves 12-15 take one row block of tile 12 each, as chain_static's
+// MIX0 does.  Weight fragments are plain loads one k-step ahead (the compiler counts vmcnt here).
+#if DSAT_ROUND_NWAVES == 16
+__global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_kernel(RoundArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    constexpr int RB = 4, BM = 16 * RB;
+    constexpr int ROWS = (BM + NT / 32 - 1) / (NT / 32);   // clause rows per half-wave
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int C = a.C, NL = a.NL;
+    const int tiles = (C + BM - 1) / BM;
+    const int lead = a.s_enable ? a.sel_lead : 0;
+    const int tb = (int)blockIdx.x - lead;
+    if (tb < 0 && (int)blockIdx.x >= a.n_sel) return;
+    const bool extra = tb < 0 || tb >= tiles;
+    const int sel_blk = tb < 0 ? (int)blockIdx.x : tb - tiles;
+    const int tile = extra ? 0 : xcd_tile(tb, tiles);
+    const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
+    const TileMetaDev tm = load_meta(a.cmeta, tile);
+    if (both_arrived(done, tm) != 0) return;
+    if (extra) {
+        DSAT_STAMP_RT_BEGIN(a);
+        DSAT_STAMP(a, 0);
+        select_sat_body<NT>(sel_blk, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
+                            a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, NL, a.round - 1, a.check_done,
+                            smem);
+        DSAT_STAMP(a, 4);
+        DSAT_STAMP_RT_END(a);
+        return;
+    }
+    const int tile_lo = tile * BM;
+    const int tile_hi = min(tile_lo + BM, C);
+    unsigned char* sbytes = reinterpret_cast<unsigned char*>(smem);
+    unsigned short* buf1 = reinterpret_cast<unsigned short*>(sbytes + a.s_buf1);
+    unsigned short* buf2 = reinterpret_cast<unsigned short*>(sbytes + a.s_buf2);
+    int* sPtr = reinterpret_cast<int*>(sbytes + a.s_idx);
+    int* sIdx = sPtr + BM + 8;
+    float* sMean = reinterpret_cast<float*>(sbytes + a.s_mean);
+    const int ldg = a.s_ld_seg, ldh = a.s_ld_hid;
+    const int pl_seg = BM * ldg, pl_hid = BM * ldh;   // elements per plane
+    const int sub = tid & 31, hw = tid >> 5;
+
+    DSAT_STAMP_RT_BEGIN(a);
+    DSAT_STAMP(a, 0);
+    const bool staged = stage_csr(a.cg_rowptr, a.cg_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr,
+                                  sIdx, a.s_idx_cap, tid);
+    if (a.cs_ready && a.round > 0) {   // R10 was finished by P1's extra blocks: load the rows, slice them
+#pragma unroll
+        for (int kq = 0; kq < ROWS; ++kq) {
+            const int r = hw + kq * (NT / 32);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile_lo + r < tile_hi) v = ld4(a.Cs + (size_t)(tile_lo + r) * F + sub * 4);
+            split_st4(buf1, pl_seg, r * ldg + sub * 4, v);
+        }
+        __syncthreads();
+    } else {   // PairNorm here, in fp32 (buf2 is free: rows, then the thread groups' partial sums), then the slices
+        float* scratch = reinterpret_cast<float*>(buf2);
+        constexpr int lds_ = F + 8;
+        pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.cgseg2, a.psum2_c, a.ncv, a.Cs, a.Cs, a.round == 0,
+                          scratch, lds_, nullptr, 0, sMean, scratch + BM * lds_, lds_, tid);
+#pragma unroll
+        for (int kq = 0; kq < ROWS; ++kq) {
+            const int r = hw + kq * (NT / 32);
+            split_st4(buf1, pl_seg, r * ldg + sub * 4, ld4(scratch + r * lds_ + sub * 4));
+        }
+        __syncthreads();
+    }
+    DSAT_STAMP(a, 1);
+    // R3 + R5 + R7 (the gather of round_p2_kernel)
+    constexpr int U = ROWS;
+    constexpr int GJ = DSAT_GJ2;
+    float4 S[U], M[U];
+    float rwv[U];
+    {
+        int e0[U], e1[U];
+        int nmax = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            S[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            M[u] = S[u];
+            const int r = hw + u * (NT / 32);
+            e0[u] = 0; e1[u] = 0;
+            rwv[u] = tile_lo + r < tile_hi ? a.rev_w[tile_lo + r] : 0.f;
+            if (tile_lo + r < tile_hi) {
+                if (staged) { e0[u] = sPtr[r]; e1[u] = sPtr[r + 1]; }
+                else { e0[u] = a.cg_rowptr[tile_lo + r]; e1[u] = a.cg_rowptr[tile_lo + r + 1]; }
+            }
+            nmax = max(nmax, e1[u] - e0[u]);
+        }
+        const unsigned zrow = 2u * (unsigned)NL;   // the all-zero row of sp / lits
+        for (int off = 0; off < nmax; off += GJ) {
+            unsigned l[U][GJ];
+            float4 sv[U][GJ], lv[U][GJ];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < GJ; ++j) {
+                    const int e = e0[u] + off + j;
+                    const bool ok = e < e1[u];
+                    int idx;
+                    if (staged) idx = sIdx[e];
+                    else idx = ok ? a.cg_lit[e] : 0;
+                    l[u][j] = ok ? (unsigned)idx : zrow;
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < GJ; ++j) {
+                    const unsigned o = l[u][j] * (unsigned)F + (unsigned)sub * 4u;
+                    sv[u][j] = ld4(a.sp + o);
+                    lv[u][j] = ld4(a.lits + o);
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < GJ; ++j) {
+                    S[u].x += sv[u][j].x; S[u].y += sv[u][j].y; S[u].z += sv[u][j].z; S[u].w += sv[u][j].w;
+                    M[u].x += lv[u][j].x; M[u].y += lv[u][j].y; M[u].z += lv[u][j].z; M[u].w += lv[u][j].w;
+                }
+        }
+        if (a.c_hv != nullptr) {   // heavy clauses: their sums come in pieces from heavy_gather_kernel
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = tile_lo + hw + u * (NT / 32);
+                if (c < tile_hi) {
+                    const int2 hv = a.c_hv[c];
+                    for (int p = 0; p < hv.y; ++p) {
+                        const float* hp = a.chpart + ((size_t)(hv.x + p) * 2) * F + sub * 4;
+                        const float4 s4 = ld4(hp), m4 = ld4(hp + F);
+                        S[u].x += s4.x; S[u].y += s4.y; S[u].z += s4.z; S[u].w += s4.w;
+                        M[u].x += m4.x; M[u].y += m4.y; M[u].z += m4.z; M[u].w += m4.w;
+                    }
+                }
+            }
+        }
+    }
+    // ---- layer 0: roles, first weight fragments, biases
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int ks0 = a.cl_ks[0], ks1 = a.cl_ks[1], nt0 = a.cl_nt[0], nt1 = a.cl_nt[1];
+    const bool mixed = nt0 == NT / 64 - 3;            // 13 tiles on 16 waves
+    const bool full0 = mixed ? wv < NT / 64 - 4 : wv < nt0;
+    const bool part0 = mixed && !full0;
+    const int tile0 = full0 ? wv : nt0 - 1;
+    const int prb = part0 ? wv - (NT / 64 - 4) : 0;
+    const bool on0 = full0 || part0, on1 = wv < nt1;
+    const uint4* wp0 = a.cl_ws[0] + ((size_t)tile0 * ks0 * 3) * 64 + lane;
+    const uint4* wp1 = a.cl_ws[1] + ((size_t)(on1 ? wv : 0) * ks1 * 3) * 64 + lane;
+    float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
+    SplitW w0;
+    w0.h = w0.m = w0.l = make_uint4(0u, 0u, 0u, 0u);
+    if (on0) {
+        w0 = split_wload(wp0, 0);
+        bv0 = *reinterpret_cast<const float4*>(a.mcl.L[0].bias + tile0 * 16 + 4 * (lane >> 4));
+    }
+    if (on1) bv1 = *reinterpret_cast<const float4*>(a.mcl.L[1].bias + wv * 16 + 4 * (lane >> 4));
+    float4 clv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {   // R5 / R7 results: messages -> buf2 now, the loss rows wait for buf1
+        const int r = hw + u * (NT / 32);
+        const int c = tile_lo + r;
+        float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+            cl = make_float4(4.f * expf(-S[u].x), 4.f * expf(-S[u].y), 4.f * expf(-S[u].z), 4.f * expf(-S[u].w));
+            stg4(a.closs4 + (size_t)c * F + sub * 4, cl);
+        }
+        clv[u] = cl;
+        const float rw = rwv[u];
+        const float4 cm = make_float4(M[u].x * rw, M[u].y * rw, M[u].z * rw, M[u].w * rw);
+        split_st4(buf2, pl_seg, r * ldg + sub * 4, cm);
+        if (a.tap_cmsg != nullptr && c < C) st4(a.tap_cmsg + (size_t)c * F + sub * 4, cm);
+    }
+    DSAT_STAMP(a, 2);
+    __syncthreads();   // state (buf1) and messages (buf2) published; the staged lists are dead
+    constexpr int KSEG = F / 32;   // k-steps per 128-column segment
+    const int xoff = (lane & 15) * ldg + 8 * (lane >> 4);
+    f32x4 acc0[RB], accp[1];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc0[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accp[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (full0) {
+        split_ksteps<RB>(wp0, 0, KSEG, ks0, w0, buf1 + xoff, pl_seg, ldg, 0, acc0);
+        split_ksteps<RB>(wp0, KSEG, 2 * KSEG, ks0, w0, buf2 + xoff, pl_seg, ldg, KSEG, acc0);
+    } else if (part0) {
+        split_ksteps<1>(wp0, 0, KSEG, ks0, w0, buf1 + xoff + prb * 16 * ldg, pl_seg, ldg, 0, accp);
+        split_ksteps<1>(wp0, KSEG, 2 * KSEG, ks0, w0, buf2 + xoff + prb * 16 * ldg, pl_seg, ldg, KSEG, accp);
+    }
+    __syncthreads();   // every wave is done with buf1's state columns
+#pragma unroll
+    for (int u = 0; u < U; ++u) split_st4(buf1, pl_seg, (hw + u * (NT / 32)) * ldg + sub * 4, clv[u]);
+    __syncthreads();
+    if (full0) split_ksteps<RB>(wp0, 2 * KSEG, 3 * KSEG, ks0, w0, buf1 + xoff, pl_seg, ldg, 2 * KSEG, acc0);
+    else if (part0) split_ksteps<1>(wp0, 2 * KSEG, 3 * KSEG, ks0, w0, buf1 + xoff + prb * 16 * ldg, pl_seg, ldg, 2 * KSEG, accp);
+    // ---- layer 0 epilogue -> slices of the hidden tile (buf2: nobody reads the messages any more)
+    SplitW w1;
+    w1.h = w1.m = w1.l = make_uint4(0u, 0u, 0u, 0u);
+    if (on1) w1 = split_wload(wp1, 0);
+    {
+        const int col = tile0 * 16 + 4 * (lane >> 4);
+        if (full0) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                split_st4(buf2, pl_hid, (rb * 16 + (lane & 15)) * ldh + col, bias_act(acc0[rb], bv0, 1));
+        } else if (part0) {
+            split_st4(buf2, pl_hid, (prb * 16 + (lane & 15)) * ldh + col, bias_act(accp[0], bv0, 1));
+        }
+        // columns between the last tile and the end of layer 1's last k-step: zeros (finite operands)
+        const int c0 = nt0 * 16, c1 = ks1 * 32;
+        for (int i = tid; i < BM * ((c1 - c0) >> 2); i += NT) {
+            const int r = i / ((c1 - c0) >> 2), cc = c0 + 4 * (i % ((c1 - c0) >> 2));
+            const uint2 z = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(buf2 + r * ldh + cc) = z;
+            *reinterpret_cast<uint2*>(buf2 + pl_hid + r * ldh + cc) = z;
+            *reinterpret_cast<uint2*>(buf2 + 2 * pl_hid + r * ldh + cc) = z;
+        }
+    }
+    __syncthreads();
+    // ---- layer 1 (one column tile per wave) and the outputs
+    f32x4 acc1[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc1[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* stage = reinterpret_cast<float*>(buf1);   // layer 0 is over: buf1 is free
+    constexpr int lds = F + 8;
+    if (on1) {
+        split_ksteps<RB>(wp1, 0, ks1, ks1, w1, buf2 + (lane & 15) * ldh + 8 * (lane >> 4), pl_hid, ldh, 0, acc1);
+        const int col = wv * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int row = rb * 16 + (lane & 15);
+            int c = tile_lo + row;
+            NO_HOIST(c);
+            const float4 v = bias_act(acc1[rb], bv1, 0);
+            if (col < F) {
+                if (c < C) stg4(a.vla + (size_t)c * F + col, v);
+            } else if (col < 2 * F) {
+                st4(stage + row * lds + (col - F), v);
+                if (c < C) stg4(a.ncv + (size_t)c * F + (col - F), v);
+            }
+        }
+    }
+    __syncthreads();
+    DSAT_STAMP(a, 3);
+    tile_colsums<BM>(tile_lo, C, tm, a.cl_seg, a.psum_c_wr, stage, lds, sMean, tid);
+    DSAT_STAMP(a, 4);
+    DSAT_STAMP_RT_END(a);
+}
+#endif
+
 // ------------------------------------------------------------------------------------- P3
 __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
@@ -1221,6 +1476,12 @@ hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {
     const int bm = 16 * rb;
     const int tiles = (a.C + bm - 1) / bm + (a.s_enable ? (a.sel_lead > 0 ? a.sel_lead : a.n_sel) : 0);
     if (tiles == 0) return hipSuccess;
+#if DSAT_ROUND_NWAVES == 16
+    if (rb == 4 && a.cl_ws[0] != nullptr) {
+        hipLaunchKernelGGL(round_p2s_kernel, dim3(tiles), dim3(NT), 0, st, a);
+        return hipGetLastError();
+    }
+#endif
     if (rb == 4) hipLaunchKernelGGL(round_p2_kernel<4>, dim3(tiles), dim3(NT), 0, st, a);
     else if (rb == 2) hipLaunchKernelGGL(round_p2_kernel<2>, dim3(tiles), dim3(NT), 0, st, a);
     else if (rb == 1) hipLaunchKernelGGL(round_p2_kernel<1>, dim3(tiles), dim3(NT), 0, st, a);
