@@ -655,6 +655,7 @@ struct dsat_session {
     int use_fused = 1;
     int p2_rb = 4;
     int p2_split = 0;   // P2 runs round_p2s_kernel (fp32 products from bf16 slices)
+    int p3_split = 0;   // P3 runs round_p3s_kernel
     float *sp = nullptr, *psum_v = nullptr, *psum_c = nullptr;
     int32_t *vmeta = nullptr, *vgseg = nullptr, *cmeta = nullptr, *cgseg = nullptr;
     std::vector<int32_t> h_vtile_seg, h_vgseg, h_ctile_seg, h_cgseg, h_vmeta, h_cmeta;
@@ -979,10 +980,10 @@ static bool plan_round(dsat_session* s) {
             r.s_idx_cap = (buf2_bytes - lists_at) / 4 - (bm + 8);
             r.s_mean = r.s_buf2 + buf2_bytes;
             if (r.s_mean + ROUND_NWAVES * 64 * 4 <= LDS * 4 && (bm * (F + 8) + ROUND_NWAVES * 64) * 4 <= seg_bytes) {
-                r.cl_ws[0] = reinterpret_cast<const uint4*>(layers[0].ws);
-                r.cl_ws[1] = reinterpret_cast<const uint4*>(layers[1].ws);
-                r.cl_ks[0] = layers[0].ksteps(); r.cl_ks[1] = ks1;
-                r.cl_nt[0] = r.mcl.L[0].ntiles; r.cl_nt[1] = r.mcl.L[1].ntiles;
+                r.sp_ws[0] = reinterpret_cast<const uint4*>(layers[0].ws);
+                r.sp_ws[1] = reinterpret_cast<const uint4*>(layers[1].ws);
+                r.sp_ks[0] = layers[0].ksteps(); r.sp_ks[1] = ks1;
+                r.sp_nt[0] = r.mcl.L[0].ntiles; r.sp_nt[1] = r.mcl.L[1].ntiles;
                 s->p2_split = 1;
             }
         }
@@ -1009,6 +1010,38 @@ static bool plan_round(dsat_session* s) {
         r.off_b = r.off_a + ROUND_BM_VAR * r.ld_a;
         r.off_mean = r.off_b + ROUND_BM_VAR * r.ld_b;
         ok = ok && (r.off_mean + ROUND_NWAVES * 64 <= LDS);
+        // the split-product form (round_p3s_kernel): [input planes | hidden A | hidden B | sums]; the staged CSR
+        // lists borrow the hidden tiles
+        s->p3_split = 0;
+        const char* sw = getenv("DSAT_P3_SPLIT");
+        bool shapes = ROUND_NWAVES == 16 && (layers.size() == 2 || layers.size() == 3) &&
+                      layers[0].kpad == 4 * F + AUX_W && !(sw != nullptr && sw[0] == '0');
+        for (int l = 0; shapes && l < r.mupd.nlayers; ++l) shapes = r.mupd.L[l].ntiles <= ROUND_NWAVES;
+        if (shapes) {
+            const int bm = ROUND_BM_VAR;
+            int ldh = 40;
+            for (size_t l = 1; l < layers.size(); ++l) ldh = std::max(ldh, layers[l].ksteps() * 32 + 8);
+            r.s_ld_seg = layers[0].ksteps() * 32 + 8;
+            r.s_ld_hid = ldh;
+            const int x_bytes = 3 * bm * r.s_ld_seg * 2, h_bytes = 3 * bm * ldh * 2;
+            r.s_buf1 = 0;
+            r.s_buf2 = x_bytes;
+            r.s_idx = r.s_buf2;
+            r.s_idx_cap = (2 * h_bytes / 4 - 2 * (bm + 8)) / 2;
+            r.s_mean = r.s_buf2 + 2 * h_bytes;
+            if (r.s_mean + ROUND_NWAVES * 64 * 4 <= LDS * 4 && bm * (F + 8) * 4 <= x_bytes && r.s_idx_cap >= 256) {
+                r.sp_layers = r.mupd.nlayers;
+                for (int l = 0; l < r.mupd.nlayers; ++l) {
+                    r.sp_ws[l] = reinterpret_cast<const uint4*>(layers[l].ws);
+                    r.sp_ks[l] = layers[l].ksteps();
+                    r.sp_nt[l] = r.mupd.L[l].ntiles;
+                }
+                s->p3_split = 1;
+            }
+        }
+        if (getenv("DSAT_DEBUG_PLAN") != nullptr)
+            fprintf(stderr, "[dsat] P3 split=%d (ldx %d ldh %d, hidden at %d, lists cap %d, sums at %d of %d bytes)\n",
+                    s->p3_split, r.s_ld_seg, r.s_ld_hid, r.s_buf2, r.s_idx_cap, r.s_mean, LDS * 4);
     }
     return ok;
 }

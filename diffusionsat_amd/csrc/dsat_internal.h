@@ -258,10 +258,12 @@ struct RoundArgs {
     // weights
     ChainSpec mq, mlit, mcl, mupd, mout;
     ChainSpec mq4, mout4;  // variables_query / variables_output blocked for 64-row tiles (P1 role B)
-    // P2 with fp32 products formed from bf16 slices (round_p2s_kernel, split_bf16.h): per layer the weights as
-    // three bf16 planes in fragment order, k-steps of 32 and column tiles; LDS plan in BYTES / bf16 elements
-    const uint4* cl_ws[2];
-    int cl_ks[2], cl_nt[2];
+    // P2 / P3 with fp32 products formed from bf16 slices (round_p2s_kernel, round_p3s_kernel, split_bf16.h): per
+    // layer the weights as three bf16 planes in fragment order, k-steps of 32 and column tiles; LDS plan in
+    // BYTES / bf16 elements (P3: s_buf1 = the input planes, s_buf2 = hidden A then hidden B)
+    const uint4* sp_ws[3];
+    int sp_layers;
+    int sp_ks[3], sp_nt[3];
     int s_buf1, s_buf2, s_idx, s_idx_cap, s_mean;   // byte offsets (s_idx_cap: ints)
     int s_ld_seg, s_ld_hid;                         // row strides of the plane images, bf16 elements
     // LDS plan (float offsets / row strides), filled by plan_round_lds

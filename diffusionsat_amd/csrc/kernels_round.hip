@@ -18,6 +18,12 @@
 #include "dsat_internal.h"
 #include "fused_common.h"
 #include "split_bf16.h"
+#ifndef DSAT_SPLIT_PD4
+#define DSAT_SPLIT_PD4 2   // ... in the 64-row split tile (four row blocks per fragment)
+#endif
+#ifndef DSAT_SPLIT_PD1
+#define DSAT_SPLIT_PD1 3   // weight k-steps in flight per wave in the 16-row split chains
+#endif
 #include "philox.h"
 
 namespace dsat {
@@ -946,65 +952,64 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
     }
     // ---- layer 0: roles, first weight fragments, biases
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int ks0 = a.cl_ks[0], ks1 = a.cl_ks[1], nt0 = a.cl_nt[0], nt1 = a.cl_nt[1];
+    const int ks0 = a.sp_ks[0], ks1 = a.sp_ks[1], nt0 = a.sp_nt[0], nt1 = a.sp_nt[1];
     const bool mixed = nt0 == NT / 64 - 3;            // 13 tiles on 16 waves
     const bool full0 = mixed ? wv < NT / 64 - 4 : wv < nt0;
     const bool part0 = mixed && !full0;
     const int tile0 = full0 ? wv : nt0 - 1;
     const int prb = part0 ? wv - (NT / 64 - 4) : 0;
     const bool on0 = full0 || part0, on1 = wv < nt1;
-    const uint4* wp0 = a.cl_ws[0] + ((size_t)tile0 * ks0 * 3) * 64 + lane;
-    const uint4* wp1 = a.cl_ws[1] + ((size_t)(on1 ? wv : 0) * ks1 * 3) * 64 + lane;
+    constexpr int PD = DSAT_SPLIT_PD4;
+    const unsigned voff = (unsigned)lane * 16u;
+    const float4* wb0 = reinterpret_cast<const float4*>(a.sp_ws[0]) + ((size_t)tile0 * ks0 * 3) * 64;
+    const float4* wb1 = reinterpret_cast<const float4*>(a.sp_ws[1]) + ((size_t)(on1 ? wv : 0) * ks1 * 3) * 64;
     float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
-    SplitW w0;
-    w0.h = w0.m = w0.l = make_uint4(0u, 0u, 0u, 0u);
-    if (on0) {
-        w0 = split_wload(wp0, 0);
-        bv0 = *reinterpret_cast<const float4*>(a.mcl.L[0].bias + tile0 * 16 + 4 * (lane >> 4));
-    }
+    if (on0) bv0 = *reinterpret_cast<const float4*>(a.mcl.L[0].bias + tile0 * 16 + 4 * (lane >> 4));
     if (on1) bv1 = *reinterpret_cast<const float4*>(a.mcl.L[1].bias + wv * 16 + 4 * (lane >> 4));
+    asm volatile("" : "+v"(bv0.x), "+v"(bv0.y), "+v"(bv0.z), "+v"(bv0.w), "+v"(bv1.x), "+v"(bv1.y), "+v"(bv1.z), "+v"(bv1.w));
+    // ---- layer 0: [state | messages | loss] through buf1 / buf2 / buf1; one loop nest per role
     float4 clv[U];
+    auto finish = [&]() {   // R5 / R7 results: messages -> buf2 now, the loss rows wait for buf1
 #pragma unroll
-    for (int u = 0; u < U; ++u) {   // R5 / R7 results: messages -> buf2 now, the loss rows wait for buf1
-        const int r = hw + u * (NT / 32);
-        const int c = tile_lo + r;
-        float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < C) {
-            cl = make_float4(4.f * expf(-S[u].x), 4.f * expf(-S[u].y), 4.f * expf(-S[u].z), 4.f * expf(-S[u].w));
-            stg4(a.closs4 + (size_t)c * F + sub * 4, cl);
+        for (int u = 0; u < U; ++u) {
+            const int r = hw + u * (NT / 32);
+            const int c = tile_lo + r;
+            float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C) {
+                cl = make_float4(4.f * expf(-S[u].x), 4.f * expf(-S[u].y), 4.f * expf(-S[u].z), 4.f * expf(-S[u].w));
+                stg4(a.closs4 + (size_t)c * F + sub * 4, cl);
+            }
+            clv[u] = cl;
+            const float rw = rwv[u];
+            const float4 cm = make_float4(M[u].x * rw, M[u].y * rw, M[u].z * rw, M[u].w * rw);
+            split_st4(buf2, pl_seg, r * ldg + sub * 4, cm);
+            if (a.tap_cmsg != nullptr && c < C) st4(a.tap_cmsg + (size_t)c * F + sub * 4, cm);
         }
-        clv[u] = cl;
-        const float rw = rwv[u];
-        const float4 cm = make_float4(M[u].x * rw, M[u].y * rw, M[u].z * rw, M[u].w * rw);
-        split_st4(buf2, pl_seg, r * ldg + sub * 4, cm);
-        if (a.tap_cmsg != nullptr && c < C) st4(a.tap_cmsg + (size_t)c * F + sub * 4, cm);
-    }
-    DSAT_STAMP(a, 2);
-    __syncthreads();   // state (buf1) and messages (buf2) published; the staged lists are dead
+        DSAT_STAMP(a, 2);
+    };
+    auto mid = [&]() {
+        lds_barrier();   // every wave is done with buf1's state columns
+#pragma unroll
+        for (int u = 0; u < U; ++u) split_st4(buf1, pl_seg, (hw + u * (NT / 32)) * ldg + sub * 4, clv[u]);
+        lds_barrier();
+    };
     constexpr int KSEG = F / 32;   // k-steps per 128-column segment
+    static_assert(KSEG % PD == 0, "a segment is a whole number of ring turns");
     const int xoff = (lane & 15) * ldg + 8 * (lane >> 4);
     f32x4 acc0[RB], accp[1];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc0[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
     accp[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (full0) {
-        split_ksteps<RB>(wp0, 0, KSEG, ks0, w0, buf1 + xoff, pl_seg, ldg, 0, acc0);
-        split_ksteps<RB>(wp0, KSEG, 2 * KSEG, ks0, w0, buf2 + xoff, pl_seg, ldg, KSEG, acc0);
-    } else if (part0) {
-        split_ksteps<1>(wp0, 0, KSEG, ks0, w0, buf1 + xoff + prb * 16 * ldg, pl_seg, ldg, 0, accp);
-        split_ksteps<1>(wp0, KSEG, 2 * KSEG, ks0, w0, buf2 + xoff + prb * 16 * ldg, pl_seg, ldg, KSEG, accp);
-    }
-    __syncthreads();   // every wave is done with buf1's state columns
-#pragma unroll
-    for (int u = 0; u < U; ++u) split_st4(buf1, pl_seg, (hw + u * (NT / 32)) * ldg + sub * 4, clv[u]);
-    __syncthreads();
-    if (full0) split_ksteps<RB>(wp0, 2 * KSEG, 3 * KSEG, ks0, w0, buf1 + xoff, pl_seg, ldg, 2 * KSEG, acc0);
-    else if (part0) split_ksteps<1>(wp0, 2 * KSEG, 3 * KSEG, ks0, w0, buf1 + xoff + prb * 16 * ldg, pl_seg, ldg, 2 * KSEG, accp);
-    // ---- layer 0 epilogue -> slices of the hidden tile (buf2: nobody reads the messages any more)
-    SplitW w1;
-    w1.h = w1.m = w1.l = make_uint4(0u, 0u, 0u, 0u);
-    if (on1) w1 = split_wload(wp1, 0);
-    {
+    if (full0)
+        split_layer_segments<RB, PD>(voff, wb0, KSEG, buf1 + xoff, buf2 + xoff, pl_seg, ldg, finish, mid, acc0);
+    else if (part0)
+        split_layer_segments<1, PD>(voff, wb0, KSEG, buf1 + xoff + prb * 16 * ldg, buf2 + xoff + prb * 16 * ldg, pl_seg, ldg,
+                                    finish, mid, accp);
+    else
+        split_layer_segments<0, PD>(voff, wb0, KSEG, buf1, buf2, pl_seg, ldg, finish, mid, accp);
+    // ---- layer 1 (one column tile per wave); its prep is layer 0's epilogue: slices of the hidden tile go to buf2
+    // (nobody reads the messages any more)
+    auto epilogue0 = [&]() {
         const int col = tile0 * 16 + 4 * (lane >> 4);
         if (full0) {
 #pragma unroll
@@ -1014,24 +1019,16 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
             split_st4(buf2, pl_hid, (prb * 16 + (lane & 15)) * ldh + col, bias_act(accp[0], bv0, 1));
         }
         // columns between the last tile and the end of layer 1's last k-step: zeros (finite operands)
-        const int c0 = nt0 * 16, c1 = ks1 * 32;
-        for (int i = tid; i < BM * ((c1 - c0) >> 2); i += NT) {
-            const int r = i / ((c1 - c0) >> 2), cc = c0 + 4 * (i % ((c1 - c0) >> 2));
-            const uint2 z = make_uint2(0u, 0u);
-            *reinterpret_cast<uint2*>(buf2 + r * ldh + cc) = z;
-            *reinterpret_cast<uint2*>(buf2 + pl_hid + r * ldh + cc) = z;
-            *reinterpret_cast<uint2*>(buf2 + 2 * pl_hid + r * ldh + cc) = z;
-        }
-    }
-    __syncthreads();
-    // ---- layer 1 (one column tile per wave) and the outputs
+        const int c0 = nt0 * 16, c1 = ks1 * 32, nq = (c1 - c0) >> 2;
+        for (int i = tid; i < BM * nq; i += NT) split_zero4(buf2, pl_hid, (i / nq) * ldh + c0 + 4 * (i % nq));
+    };
     f32x4 acc1[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc1[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
     float* stage = reinterpret_cast<float*>(buf1);   // layer 0 is over: buf1 is free
     constexpr int lds = F + 8;
     if (on1) {
-        split_ksteps<RB>(wp1, 0, ks1, ks1, w1, buf2 + (lane & 15) * ldh + 8 * (lane >> 4), pl_hid, ldh, 0, acc1);
+        split_layer<RB, PD>(voff, wb1, ks1, buf2 + (lane & 15) * ldh + 8 * (lane >> 4), pl_hid, ldh, epilogue0, acc1);
         const int col = wv * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
@@ -1046,6 +1043,8 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
                 if (c < C) stg4(a.ncv + (size_t)c * F + (col - F), v);
             }
         }
+    } else {
+        split_layer<0, PD>(voff, wb1, ks1, buf2, pl_hid, ldh, epilogue0, accp);
     }
     __syncthreads();
     DSAT_STAMP(a, 3);
@@ -1242,6 +1241,217 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3_kern
         DSAT_STAMP_RT_END(a);
     }
 }
+
+// ------------------------------------------------------------------------------------- P3, split products
+// round_p3_kernel with update_gate's products formed from bf16 slices (split_bf16.h).  The unit
+// [grad | variables | aux | loss_pos | loss_neg] is written to LDS as three bf16 planes (16 x 544 + pad), the
+// hidden tiles likewise; the CSR lists are staged in the hidden tiles' space, the fp32 stage of the column sums
+// reuses the input planes.  With 16-row tiles the chain is bound by the weight stream (6 bytes per weight through
+// the CU's 64 B/clk vector-memory path), not by the MFMA pipe.
+#if DSAT_ROUND_NWAVES == 16
+__global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_kernel(RoundArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    constexpr int BM = ROUND_BM_VAR;
+    constexpr int PASSES = BM / ROUND_NWAVES;   // variables per wave
+#ifndef DSAT_GJ3
+#define DSAT_GJ3 4
+#endif
+    constexpr int GJ = DSAT_GJ3;                // clause rows in flight per literal (x PASSES x 2 arrays)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int N = a.N, NL = a.NL;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
+    const TileMetaDev tm = load_meta(a.vmeta, tile);
+    if (both_arrived(done, tm) != 0) return;
+    if (a.sel_zero && blockIdx.x == 0)   // multi-part select adds its counts up: start the next one from zero
+        for (int g = tid; g < a.G; g += NT) a.graph_unsat[g] = 0;
+    const int tile_lo = tile * BM;
+    const int tile_hi = min(tile_lo + BM, N);
+    unsigned char* sbytes = reinterpret_cast<unsigned char*>(smem);
+    unsigned short* xs = reinterpret_cast<unsigned short*>(sbytes + a.s_buf1);
+    const int ldx = a.s_ld_seg, ldh = a.s_ld_hid;
+    const int xpl = BM * ldx;                          // elements per input plane
+    unsigned short* hA = reinterpret_cast<unsigned short*>(sbytes + a.s_buf2);
+    unsigned short* hB = hA + 3 * BM * ldh;
+    float* sPart = reinterpret_cast<float*>(sbytes + a.s_mean);
+    // unit = [variables_grad | variables | aux | loss_pos | loss_neg]        (query_sat.py:277)
+    constexpr int OFF_V = F, OFF_AUX = 2 * F, OFF_POS = 2 * F + AUX_W, OFF_NEG = 3 * F + AUX_W;
+    DSAT_STAMP_RT_BEGIN(a);
+    DSAT_STAMP(a, 0);
+    DSAT_STAMP(a, 4);
+    {   // R4 + R11: one wave per variable, half 0 = literal +v, half 1 = literal -v
+        const int sub = lane & 31, half = lane >> 5;
+        // literal -> clause lists of the tile's +v rows and -v rows -> LDS (the hidden tiles are free until layer 0)
+        int* sPtr0 = reinterpret_cast<int*>(sbytes + a.s_idx);
+        int* sPtr1 = sPtr0 + BM + 8;
+        int* sIdx0 = sPtr1 + BM + 8;
+        const int cap = a.s_idx_cap;
+        int* sIdx1 = sIdx0 + cap;
+        const int nrows = tile_hi - tile_lo;
+        const bool st0 = stage_csr(a.l_rowptr, a.l_clause, tile_lo, nrows, tm.e_base0, tm.e_end0, sPtr0, sIdx0, cap, tid);
+        const bool st1 = stage_csr(a.l_rowptr, a.l_clause, NL + tile_lo, nrows, tm.e_base1, tm.e_end1, sPtr1, sIdx1, cap, tid);
+        const bool staged = st0 && st1;
+        // rows that do not depend on the lists: q (half 0) and the carried state (half 1)
+        float4 rowv[PASSES], qrow[PASSES];
+        float wdeg[PASSES], wv[PASSES];
+        int2 hv[PASSES];
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            const int v = tile_lo + wave + u * ROUND_NWAVES;
+            rowv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            qrow[u] = rowv[u];
+            wdeg[u] = 0.f; wv[u] = 0.f;
+            hv[u] = make_int2(-1, 0);
+            if (v < N) {
+                if (a.l_hv != nullptr) hv[u] = a.l_hv[v + half * NL];
+                qrow[u] = ld4(a.q + (size_t)v * F + sub * 4);
+                if (half == 1) rowv[u] = ld4(a.V + (size_t)v * F + sub * 4);
+                wdeg[u] = a.deg_w[v + half * NL];
+                wv[u] = a.vdeg_w[v];
+            }
+        }
+        if (tid < BM) {   // aux columns of the row, and the zero columns up to the end of the last k-step
+            const int n = tile_lo + tid;
+            float4 v[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
+                           make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            if (n < N) {
+                const float* src = a.aux + ((size_t)a.round * N + n) * AUX_W;
+                v[0] = ld4(src); v[1] = ld4(src + 4); v[2] = ld4(src + 8); v[3] = ld4(src + 12);
+            }
+            static_assert(AUX_W == 16, "aux row");
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) split_st4(xs, xpl, tid * ldx + OFF_AUX + 4 * q4, v[q4]);
+            for (int c = OFF_NEG + F; c < a.sp_ks[0] * 32; c += 4) split_zero4(xs, xpl, tid * ldx + c);
+        }
+        __syncthreads();   // lists staged
+        DSAT_STAMP(a, 5);
+        float4 M[PASSES], VL[PASSES];
+        int e0[PASSES], e1[PASSES];
+        int nmax = 0;
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            M[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            VL[u] = M[u];
+            const int r = wave + u * ROUND_NWAVES;
+            e0[u] = 0; e1[u] = 0;
+            if (tile_lo + r < N) {
+                if (staged) {
+                    const int* sp_ = half ? sPtr1 : sPtr0;
+                    e0[u] = sp_[r]; e1[u] = sp_[r + 1];
+                } else {
+                    const int lit = tile_lo + r + half * NL;
+                    e0[u] = a.l_rowptr[lit]; e1[u] = a.l_rowptr[lit + 1];
+                }
+            }
+            nmax = max(nmax, e1[u] - e0[u]);
+        }
+        nmax = max(nmax, __shfl_xor(nmax, 32));   // both halves run the same trip count
+        const int* sIdx = half ? sIdx1 : sIdx0;
+        // Branch-free: a conditional load would make the compiler wait for memory at every
+        // join, serialising the rows.  List slots past a row's end read the all-zero row C
+        // (dsat_api.hip carve), so nothing is masked; offsets are 32-bit (SGPR base + VGPR).
+        const unsigned zrow = (unsigned)a.CL;
+        for (int off = 0; off < nmax; off += GJ) {
+            unsigned ci[PASSES][GJ];
+            float4 cv[PASSES][GJ], vv[PASSES][GJ];
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u)
+#pragma unroll
+                for (int j = 0; j < GJ; ++j) {
+                    const int e = e0[u] + off + j;
+                    const bool ok = e < e1[u];
+                    int idx;
+                    if (staged) idx = sIdx[e];              // LDS: reading past the list is harmless
+                    else idx = ok ? a.l_clause[e] : 0;      // rare path (lists larger than the LDS budget)
+                    ci[u][j] = ok ? (unsigned)idx : zrow;
+                }
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u)
+#pragma unroll
+                for (int j = 0; j < GJ; ++j) {
+                    const unsigned o = ci[u][j] * (unsigned)F + (unsigned)sub * 4u;
+                    cv[u][j] = ld4(a.closs4 + o);
+                    vv[u][j] = ld4(a.vla + o);
+                }
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u)
+#pragma unroll
+                for (int j = 0; j < GJ; ++j) {
+                    M[u].x += cv[u][j].x; M[u].y += cv[u][j].y; M[u].z += cv[u][j].z; M[u].w += cv[u][j].w;
+                    VL[u].x += vv[u][j].x; VL[u].y += vv[u][j].y; VL[u].z += vv[u][j].z; VL[u].w += vv[u][j].w;
+                }
+        }
+        if (a.l_hv != nullptr) {   // heavy rows: their sums come in pieces from heavy_gather_kernel
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u) {
+                for (int p = 0; p < hv[u].y; ++p) {
+                    const float* hp = a.hpart + ((size_t)(hv[u].x + p) * 2) * F + sub * 4;
+                    const float4 m4 = ld4(hp), v4 = ld4(hp + F);
+                    M[u].x += m4.x; M[u].y += m4.y; M[u].z += m4.z; M[u].w += m4.w;
+                    VL[u].x += v4.x; VL[u].y += v4.y; VL[u].z += v4.z; VL[u].w += v4.w;
+                }
+            }
+        }
+        DSAT_STAMP(a, 6);
+        // the last part of the tile preparation runs inside the chain, after it has asked for
+        // its first weight fragments (run_chain's `prep`), and the chain takes the barrier
+        auto finish = [&]() {
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            const int r = wave + u * ROUND_NWAVES;
+            const float dw = wdeg[u];
+            const float4 vls = make_float4(VL[u].x * dw, VL[u].y * dw, VL[u].z * dw, VL[u].w * dw);
+            split_st4(xs, xpl, r * ldx + (half ? OFF_NEG : OFF_POS) + sub * 4, vls);
+            if (a.tap_vloss != nullptr && tile_lo + r < N)
+                st4(a.tap_vloss + ((size_t)(tile_lo + r) + (size_t)half * NL) * F + sub * 4, vls);
+            float4 Mo;
+            Mo.x = __shfl_xor(M[u].x, 32); Mo.y = __shfl_xor(M[u].y, 32);
+            Mo.z = __shfl_xor(M[u].z, 32); Mo.w = __shfl_xor(M[u].w, 32);
+            {   // closed form of the inner tape (closs4 = 4*closs, 0.25 is exact); each half-wave
+                // computes two of its lane's four columns: half 0 -> .x .y, half 1 -> .z .w
+                const float4 qv = qrow[u];
+                const float vw = wv[u];
+                const float q0 = half ? qv.z : qv.x, q1 = half ? qv.w : qv.y;
+                const float p0 = half ? Mo.z : M[u].x, p1 = half ? Mo.w : M[u].y;   // sums over +v clauses
+                const float n0 = half ? M[u].z : Mo.x, n1 = half ? M[u].w : Mo.y;   // sums over -v clauses
+                float s0, sn0, s1, sn1;
+                sigmoid_pair(q0, s0, sn0);
+                sigmoid_pair(q1, s1, sn1);
+                float2 g;
+                g.x = (-s0 * (p0 * 0.25f) + sn0 * (n0 * 0.25f)) * vw;
+                g.y = (-s1 * (p1 * 0.25f) + sn1 * (n1 * 0.25f)) * vw;
+                split_st2(xs, xpl, r * ldx + sub * 4 + 2 * half, g);
+                if (a.tap_grad != nullptr && tile_lo + r < N)
+                    *reinterpret_cast<float2*>(a.tap_grad + (size_t)(tile_lo + r) * F + sub * 4 + 2 * half) = g;
+            }
+            if (half == 1) split_st4(xs, xpl, r * ldx + OFF_V + sub * 4, rowv[u]);
+        }
+        DSAT_STAMP(a, 1);
+        };
+        // R12: new_variables = update_gate(unit)
+        float* newv = a.newv;
+        float* stage = reinterpret_cast<float*>(xs);   // the input planes are dead once layer 0 has run
+        const int lds = F + 8;
+        SplitChain sc;
+        sc.nlayers = a.sp_layers;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) sc.L[l] = SplitLayer{a.sp_ws[l], a.mupd.L[l].bias, a.sp_ks[l], a.sp_nt[l]};
+        const int wvu = __builtin_amdgcn_readfirstlane(wave);
+        split_chain<1, NT, DSAT_SPLIT_PD1>(sc, xs, ldx, hA, hB, ldh, wvu, lane, tid, [=](int row, int col, float4 v) {
+            int n = tile_lo + row;
+            NO_HOIST(n);
+            if (col < F) {
+                st4(stage + row * lds + col, v);
+                if (n < N) stg4(newv + (size_t)n * F + col, v);
+            }
+        }, finish);
+        DSAT_STAMP(a, 2);
+        tile_colsums<BM>(tile_lo, N, tm, a.var_seg, a.psum_v, stage, lds, sPart, tid);
+        DSAT_STAMP(a, 3);
+        DSAT_STAMP_RT_END(a);
+    }
+}
+#endif
 
 // ------------------------------------------------------------------------------------- PairNorm, level 2
 // A graph spread over many tiles (one 10 000-variable formula = 625 variable tiles) would have every
@@ -1477,7 +1687,7 @@ hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {
     const int tiles = (a.C + bm - 1) / bm + (a.s_enable ? (a.sel_lead > 0 ? a.sel_lead : a.n_sel) : 0);
     if (tiles == 0) return hipSuccess;
 #if DSAT_ROUND_NWAVES == 16
-    if (rb == 4 && a.cl_ws[0] != nullptr) {
+    if (rb == 4 && a.sp_ws[0] != nullptr) {
         hipLaunchKernelGGL(round_p2s_kernel, dim3(tiles), dim3(NT), 0, st, a);
         return hipGetLastError();
     }
@@ -1490,6 +1700,12 @@ hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {
 }
 hipError_t launch_round_p3(const RoundArgs& a, hipStream_t st) {
     const int tiles = (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
+#if DSAT_ROUND_NWAVES == 16
+    if (a.sp_ws[0] != nullptr) {
+        hipLaunchKernelGGL(round_p3s_kernel, dim3(tiles), dim3(NT), 0, st, a);
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL(round_p3_kernel, dim3(tiles), dim3(NT), 0, st, a);
     return hipGetLastError();
 }
