@@ -41,6 +41,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = vector fp32 peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+# Kernels that form an fp32 product from six bf16-slice products (csrc/split_bf16.h) run on the bf16 matrix pipe:
+# dense bf16 MFMA peak (16x the fp32-input rate, same guide) / 6 = the fp32-equivalent ceiling of that form
+PEAK_MFMA_BF16_TFLOPS = 16 * PEAK_MFMA_F32_TFLOPS
+PEAK_SPLIT_F32EQ_TFLOPS = PEAK_MFMA_BF16_TFLOPS / 6
 
 DEFAULT_STEPS = {2: 32, 3: 64, 4: 32, 5: 128}     # one full sample of the config's T
 
@@ -317,6 +321,11 @@ def main():
             "value": value, "unit": "denoising-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # f32 in, f32 out, f32 accumulation everywhere; where arithmetic_note says so, an MLP's f32 products are
+            # formed exactly-to-f32-rounding from bf16 slices (same tolerances against the f64 oracle as the f32 MFMA)
+            "arithmetic_note": ("clause_mlp" if sess.split_mask() & 1 else "") + (" update_gate" if sess.split_mask() & 2 else "")
+                               + (": fp32 products as six bf16-slice products on v_mfma_f32_16x16x32_bf16 (csrc/split_bf16.h); "
+                                  "all else v_mfma_f32_16x16x4_f32" if sess.split_mask() else "v_mfma_f32_16x16x4_f32 everywhere"),
             "solved_fraction": solved_fraction,
             "repeats": {"n": len(ms), "ms_per_step_median": float(np.median(ms)), "ms_per_step_min": min(ms),
                         "ms_per_step_max": max(ms), "ms_per_step_all": [round(x, 5) for x in ms],
@@ -363,12 +372,19 @@ def main():
                     continue
             default_cfg2 = args.config == 2 and (args.graphs, args.vars) == (31, 100)
             roofs = {}
+            mask = sess.split_mask()
+            split = {"round_p2_clause": bool(mask & 1), "round_p3_var_update": bool(mask & 2)}
             for k, fl in per_launch.items():
                 if k in prof and prof[k]["launches"] > 0:
                     us = prof[k]["avg_us"]
                     ach = fl / (us * 1e-6) / 1e12
-                    roofs[k] = {"bound": "mfma", "kernel": kern_name[k], "achieved": ach,
-                                "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS,
+                    sp = split.get(k, False)
+                    peak = PEAK_SPLIT_F32EQ_TFLOPS if sp else PEAK_MFMA_F32_TFLOPS
+                    roofs[k] = {"bound": "mfma", "kernel": kern_name[k].replace("_kernel<4>", "s_kernel").replace("p3_kernel", "p3s_kernel") if sp else kern_name[k],
+                                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                "pipe": ("v_mfma_f32_16x16x32_bf16, six bf16-slice products per fp32 product: achieved = "
+                                         "algorithmic fp32 flops / time, peak = dense bf16 MFMA peak %.0f / 6"
+                                         % PEAK_MFMA_BF16_TFLOPS) if sp else "v_mfma_f32_16x16x4_f32",
                                 "traffic": traffic.get(k) if default_cfg2 else None,
                                 "avg_launch_us": us,
                                 "launches_per_step": prof[k]["launches"] / steps_prof,

@@ -2231,6 +2231,11 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t* __restric
 }
 }  // namespace dsat
 
+extern "C" int32_t dsat_session_split_mask(const dsat_session* s) {
+    if (s == nullptr || !s->use_fused) return 0;
+    return (s->p2_split ? 1 : 0) | (s->p3_split ? 2 : 0);
+}
+
 extern "C" int64_t dsat_session_packed_bytes(const dsat_session* s, int32_t* offsets_out) {
     if (!s) return -1;
     if (offsets_out)

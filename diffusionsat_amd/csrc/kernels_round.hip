@@ -239,6 +239,8 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
 }
 
 // Column sums of the tile's new rows (staged in LDS, ld = ldT), one segment per graph touched.
+// Its barriers order LDS only: the tile's write-through output stores are still being acknowledged when the
+// sums start (a __syncthreads() here would wait ~6 k cycles for them).
 // Four thread groups each add a quarter of the segment's rows; the quarters are combined in
 // a fixed order.  sPart: NT floats of LDS.
 template <int BM>
@@ -260,14 +262,14 @@ __device__ __forceinline__ void tile_colsums(int tile_lo, int rows, const TileMe
         float sacc = 0.f;
         for (int r = a0; r < a1; ++r) sacc += sT[(r - tile_lo) * ldT + c];
         sPart[tid] = sacc;
-        __syncthreads();
+        lds_barrier();
         if (tid < F) {
             float t = sPart[tid];
 #pragma unroll
             for (int k = 1; k < NG; ++k) t += sPart[k * F + tid];
             psum[(size_t)(tm.seg_base + ord) * F + tid] = t;
         }
-        __syncthreads();
+        lds_barrier();
         ++ord;
     }
 }
@@ -306,7 +308,7 @@ __device__ __forceinline__ void run_chain(const ChainSpec& m, const float* sIn, 
             else
                 chain_static<4, 16, 1, 1, 0>(S0, S1, S2, sIn, ldin, bufA, ldA, bufB, ldB, wv, lane, final_store, true, prep);
         }
-        __syncthreads();
+        lds_barrier();   // LDS only: the outputs' write-through stores need not be acknowledged here
         return;
     }
     prep();
@@ -1007,6 +1009,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
                                     finish, mid, accp);
     else
         split_layer_segments<0, PD>(voff, wb0, KSEG, buf1, buf2, pl_seg, ldg, finish, mid, accp);
+    DSAT_STAMP(a, 5);
     // ---- layer 1 (one column tile per wave); its prep is layer 0's epilogue: slices of the hidden tile go to buf2
     // (nobody reads the messages any more)
     auto epilogue0 = [&]() {
@@ -1029,6 +1032,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
     constexpr int lds = F + 8;
     if (on1) {
         split_layer<RB, PD>(voff, wb1, ks1, buf2 + (lane & 15) * ldh + 8 * (lane >> 4), pl_hid, ldh, epilogue0, acc1);
+        DSAT_STAMP(a, 6);
         const int col = wv * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
@@ -1046,7 +1050,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
     } else {
         split_layer<0, PD>(voff, wb1, ks1, buf2, pl_hid, ldh, epilogue0, accp);
     }
-    __syncthreads();
+    lds_barrier();   // the stage is complete; the global stores drain while the sums are taken
     DSAT_STAMP(a, 3);
     tile_colsums<BM>(tile_lo, C, tm, a.cl_seg, a.psum_c_wr, stage, lds, sMean, tid);
     DSAT_STAMP(a, 4);

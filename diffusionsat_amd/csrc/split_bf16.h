@@ -299,7 +299,7 @@ __device__ __forceinline__ void split_chain(const SplitChain& m, const unsigned 
     pin_bias(bv);   // the biases are ordinary loads: complete them before the asm loads start
     if (on[0]) split_prime<PD>(ring, voff, wb[0], m.L[0].ksteps);
     prep();
-    __syncthreads();
+    lds_barrier();
     const unsigned short* src = in;
     int ld = ld_in;
 #pragma unroll
@@ -330,7 +330,7 @@ __device__ __forceinline__ void split_chain(const SplitChain& m, const unsigned 
             // columns between this layer's last tile and the end of the next layer's last k-step: zeros
             const int c0 = m.L[l].ntiles * 16, c1 = m.L[l + 1].ksteps * 32, nq = (c1 - c0) >> 2;
             for (int i = tid; i < ROWS * nq; i += NTHREADS) split_zero4(dst, ROWS * ldh, (i / nq) * ldh + c0 + 4 * (i % nq));
-            __syncthreads();
+            lds_barrier();
             src = dst;
             ld = ldh;
         } else if (on[l]) {
@@ -340,7 +340,7 @@ __device__ __forceinline__ void split_chain(const SplitChain& m, const unsigned 
                             make_float4(acc[rb][0] + bv[l].x, acc[rb][1] + bv[l].y, acc[rb][2] + bv[l].z, acc[rb][3] + bv[l].w));
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 }  // namespace dsat

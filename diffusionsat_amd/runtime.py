@@ -369,6 +369,11 @@ class Session:
         """Drop solved copies from a batch of identical copies between denoising steps (``dsat_session_set_retire``)."""
         _lib.check(_lib.load().dsat_session_set_retire(self.handle, int(enable)))
 
+    def split_mask(self) -> int:
+        """bit 0: the clause tile, bit 1: the variable-update tile run their MLP products as bf16 slices on
+        the bf16 matrix pipe (``dsat_session_split_mask``)."""
+        return int(_lib.load().dsat_session_split_mask(self.handle))
+
     def set_profile(self, enable: bool):
         _lib.check(_lib.load().dsat_session_set_profile(self.handle, int(enable)))
 

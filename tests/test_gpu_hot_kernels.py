@@ -57,13 +57,26 @@ def _instances(kind):
     return make_all(kind)
 
 
+# the three forms the round runs in: fused tiles with the clause / update MLPs on the bf16 pipe (fp32 products from
+# bf16 slices, the default), fused tiles on v_mfma_f32_16x16x4_f32 only, and the per-layer kernels
+VARIANTS = ["fused", "fused_f32mfma", "per_layer"]
+
+
 def _session(rt, batch, ws, max_rounds, fused):
-    if not fused:
-        os.environ["DSAT_FUSED"] = "0"
+    env = {"per_layer": {"DSAT_FUSED": "0"}, "fused_f32mfma": {"DSAT_P2_SPLIT": "0", "DSAT_P3_SPLIT": "0"}}.get(fused, {})
+    if fused is False:
+        env = {"DSAT_FUSED": "0"}
+    os.environ.update(env)
     try:
-        return rt.Session(rt.Graph(batch), rt.Weights(ws), max_rounds=max_rounds)
+        s = rt.Session(rt.Graph(batch), rt.Weights(ws), max_rounds=max_rounds)
     finally:
-        os.environ.pop("DSAT_FUSED", None)
+        for k in env:
+            os.environ.pop(k, None)
+    if fused == "fused_f32mfma":
+        assert s.split_mask() == 0
+    if fused == "fused":
+        assert s.split_mask() == 3        # the released layout runs both split-product tiles
+    return s
 
 
 # oracle trace key -> (tap key, which rows)
@@ -74,13 +87,13 @@ TAP_MAP = [("query", "query"), ("literals", "literals"), ("clauses_loss4", "clau
            ("variables", "variables"), ("clause_state", "clause_state")]
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_layer"])
+@pytest.mark.parametrize("fused", VARIANTS)
 @pytest.mark.parametrize("kind", ["3sat", "ragged", "medium", "irregular"])
 def test_round_intermediates_match_oracle_trace(rt, kind, fused):
     """Every intermediate tensor of rounds 0, 1 and 31 against the oracle trace.  The step runs 33
     rounds so that the clause state of round 31 (finished while round 32 runs on the fused path) is
     available; rounds are causal, so rounds 0..31 are those of a 32-round step."""
-    if not fused and kind in ("medium", "irregular"):
+    if fused == "per_layer" and kind in ("medium", "irregular"):
         pytest.skip("per-layer path: two graph kinds are enough (it has its own operator tests)")
     insts, batch, data = _instances(kind)
     ws = oracle_weights(7)
@@ -145,7 +158,7 @@ def test_op_mlp_ex_fused_chain(rt, mlp, rb, nwaves):
     assert np.abs(y - y0).max() < 1e-5 + 1e-4 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_layer"])
+@pytest.mark.parametrize("fused", VARIANTS)
 @pytest.mark.parametrize("case", [0, 1])
 def test_mid_loop_early_exit_matches_fixture(rt, case, fused):
     """is_batch_sat fires at a middle round (model/query_sat.py:330-338): ``steps_taken``, the logits of

@@ -498,8 +498,8 @@ def _fuzz_instances(seed):
 @pytest.mark.parametrize("seed", range(8))
 def test_random_batch_structures_match_oracle(rt, seed):
     """Structure fuzz (the reference batches whatever the dataset yields, data/k_sat.py:60-117: any mix of
-    sizes): 3 rounds of logits, the per-graph clause loss and the SAT flags against the oracle, on both
-    the fused and the per-layer path."""
+    sizes): 3 rounds of logits against the oracle on the three kernel forms (fused tiles with split products,
+    fused tiles on the fp32 MFMA, per-layer kernels), then is_graph_sat and the packed bits."""
     insts = _fuzz_instances(seed)
     from diffusionsat_amd.batch import make_batch
     batch = make_batch(insts)
@@ -512,14 +512,15 @@ def test_random_batch_structures_match_oracle(rt, seed):
                            dt=np.float32, trace=("logits",))
     g = rt.Graph(batch)
     w = rt.Weights(ws)
-    for fused in (1, 0):
-        os.environ["DSAT_FUSED"] = str(fused)
+    for env in ({}, {"DSAT_P2_SPLIT": "0", "DSAT_P3_SPLIT": "0"}, {"DSAT_FUSED": "0"}):
+        os.environ.update(env)
         try:
             s = rt.Session(g, w, max_rounds=rounds)
             out = s.diffusion_step(0.3, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds,
                                    early_exit=False, want_round_logits=True)
         finally:
-            os.environ.pop("DSAT_FUSED", None)
+            for k in env:
+                os.environ.pop(k, None)
         got = out["round_logits"].cpu().numpy()
         for r in range(rounds):
             _close(got[r], ref["trace"]["logits"][r], 0, LOGIT_TOL)

@@ -85,7 +85,11 @@ def table(stamps, meta):
         lines.append("%s: %d tiles; median %.0f cycles per tile (max %.0f) at %.2f GHz = %.1f us; MFMA issue floor "
                      "%d cycles = %.0f %%" % (k, t.shape[0], np.median(tot), tot.max(), ghz,
                                               np.median(tot) / (ghz * 1e3), floor, 100 * floor / np.median(tot)))
-        for name, lo, hi in PHASES[k]:
+        phases = list(PHASES[k])
+        if k == "round_p2" and (t[:, 5] > 0).all():    # the split-product tile stamps its layers
+            phases[3:3] = [("  layer 0 (three segments)", 2, 5), ("  layer 1 (epilogue 0, barrier, k-loop)", 5, 6),
+                           ("  outputs", 6, 3)]
+        for name, lo, hi in phases:
             d = t[:, hi] - t[:, lo]
             kk["phases"][name.strip()] = {"median": float(np.median(d)), "max": float(d.max())}
             lines.append("    %-34s median %8.0f  max %8.0f cycles  (%4.1f %%)" % (
