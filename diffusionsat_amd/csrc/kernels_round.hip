@@ -1314,18 +1314,14 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
                 wv[u] = a.vdeg_w[v];
             }
         }
-        if (tid < BM) {   // aux columns of the row, and the zero columns up to the end of the last k-step
-            const int n = tile_lo + tid;
-            float4 v[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
-                           make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-            if (n < N) {
-                const float* src = a.aux + ((size_t)a.round * N + n) * AUX_W;
-                v[0] = ld4(src); v[1] = ld4(src + 4); v[2] = ld4(src + 8); v[3] = ld4(src + 12);
-            }
+        if (tid < 4 * BM) {   // aux columns of the rows (one float4 per thread), and the zero columns up to the end of
+            const int r = tid >> 2, q4 = tid & 3;   // the last k-step
+            const int n = tile_lo + r;
             static_assert(AUX_W == 16, "aux row");
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) split_st4(xs, xpl, tid * ldx + OFF_AUX + 4 * q4, v[q4]);
-            for (int c = OFF_NEG + F; c < a.sp_ks[0] * 32; c += 4) split_zero4(xs, xpl, tid * ldx + c);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < N) v = ld4(a.aux + ((size_t)a.round * N + n) * AUX_W + 4 * q4);
+            split_st4(xs, xpl, r * ldx + OFF_AUX + 4 * q4, v);
+            for (int c = OFF_NEG + F + 4 * q4; c < a.sp_ks[0] * 32; c += 16) split_zero4(xs, xpl, r * ldx + c);
         }
         __syncthreads();   // lists staged
         DSAT_STAMP(a, 5);
@@ -1436,19 +1432,22 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
         float* newv = a.newv;
         float* stage = reinterpret_cast<float*>(xs);   // the input planes are dead once layer 0 has run
         const int lds = F + 8;
-        SplitChain sc;
-        sc.nlayers = a.sp_layers;
-#pragma unroll
-        for (int l = 0; l < 3; ++l) sc.L[l] = SplitLayer{a.sp_ws[l], a.mupd.L[l].bias, a.sp_ks[l], a.sp_nt[l]};
         const int wvu = __builtin_amdgcn_readfirstlane(wave);
-        split_chain<1, NT, DSAT_SPLIT_PD1>(sc, xs, ldx, hA, hB, ldh, wvu, lane, tid, [=](int row, int col, float4 v) {
+        auto final_store = [=](int row, int col, float4 v) {
             int n = tile_lo + row;
             NO_HOIST(n);
             if (col < F) {
                 st4(stage + row * lds + col, v);
                 if (n < N) stg4(newv + (size_t)n * F + col, v);
             }
-        }, finish);
+        };
+        {
+            SplitChain sc;
+            sc.nlayers = a.sp_layers;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) sc.L[l] = SplitLayer{a.sp_ws[l], a.mupd.L[l].bias, a.sp_ks[l], a.sp_nt[l]};
+            split_chain<1, NT, DSAT_SPLIT_PD1>(sc, xs, ldx, hA, hB, ldh, wvu, lane, tid, final_store, finish);
+        }
         DSAT_STAMP(a, 2);
         tile_colsums<BM>(tile_lo, N, tm, a.var_seg, a.psum_v, stage, lds, sPart, tid);
         DSAT_STAMP(a, 3);

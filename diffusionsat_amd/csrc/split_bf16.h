@@ -98,13 +98,13 @@ __device__ __forceinline__ void split_ksteps(const uint4* __restrict__ wp, int s
 // are clamped to the last step, so exactly 3*PD loads are in flight at every wait of the main loop.
 struct SplitSlot { sf32x4 h, m, l; };
 
-template <int PD>
+template <int PD, int P0 = 0, int P1 = PD>   // slots [P0, P1): the prime may be issued in two parts, in slot order
 __device__ __forceinline__ void split_prime(SplitSlot (&ring)[PD], unsigned voff, const float4* __restrict__ wbase,
                                             int stot) {
     static_assert(3 * PD <= 63, "vmcnt field is 6 bits");
     const int last = stot - 1;
 #pragma unroll
-    for (int p = 0; p < PD; ++p) {
+    for (int p = P0; p < P1; ++p) {
         const float4* sb = wbase + (size_t)(p < last ? p : last) * 192;
         gload_b128(ring[p].h, voff, sb);
         gload_b128(ring[p].m, voff, sb + 64);
@@ -297,8 +297,11 @@ __device__ __forceinline__ void split_chain(const SplitChain& m, const unsigned 
     for (int l = 0; l < 3; ++l)
         wb[l] = reinterpret_cast<const float4*>(m.L[l < m.nlayers ? l : 0].ws) + ((size_t)(on[l] ? wv : 0) * m.L[l < m.nlayers ? l : 0].ksteps * 3) * 64;
     pin_bias(bv);   // the biases are ordinary loads: complete them before the asm loads start
-    if (on[0]) split_prime<PD>(ring, voff, wb[0], m.L[0].ksteps);
+    // the first layer's prime in two parts: the registers prep() still holds (a gather's sums) cap what fits before it
+    constexpr int PRE = PD < 2 ? PD : 2;
+    if (on[0]) split_prime<PD, 0, PRE>(ring, voff, wb[0], m.L[0].ksteps);
     prep();
+    if (on[0]) split_prime<PD, PRE, PD>(ring, voff, wb[0], m.L[0].ksteps);
     lds_barrier();
     const unsigned short* src = in;
     int ld = ld_in;
