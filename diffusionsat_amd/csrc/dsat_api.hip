@@ -968,8 +968,8 @@ static bool plan_round(dsat_session* s) {
             r.mcl.L[0].ntiles <= ROUND_NWAVES && r.mcl.L[1].ntiles <= ROUND_NWAVES &&
             r.mcl.L[0].ntiles * 16 <= layers[1].ksteps() * 32 && !(sw != nullptr && sw[0] == '0')) {
             const int ks1 = layers[1].ksteps();
-            r.s_ld_seg = F + 8;
-            r.s_ld_hid = ks1 * 32 + 8;
+            r.s_ld_seg = F + 16;          // row stride == 32 bytes mod 64: conflict-free fragment reads (split_bf16.h)
+            r.s_ld_hid = ks1 * 32 + 16;
             const int seg_bytes = 3 * bm * r.s_ld_seg * 2, hid_bytes = 3 * bm * r.s_ld_hid * 2;
             const int scratch_bytes = (bm + ROUND_NWAVES * 64 / F) * (F + 8) * 4;   // PairNorm rows + partial sums
             const int lists_at = std::max(seg_bytes, scratch_bytes);
@@ -1019,9 +1019,9 @@ static bool plan_round(dsat_session* s) {
         for (int l = 0; shapes && l < r.mupd.nlayers; ++l) shapes = r.mupd.L[l].ntiles <= ROUND_NWAVES;
         if (shapes) {
             const int bm = ROUND_BM_VAR;
-            int ldh = 40;
-            for (size_t l = 1; l < layers.size(); ++l) ldh = std::max(ldh, layers[l].ksteps() * 32 + 8);
-            r.s_ld_seg = layers[0].ksteps() * 32 + 8;
+            int ldh = 48;
+            for (size_t l = 1; l < layers.size(); ++l) ldh = std::max(ldh, layers[l].ksteps() * 32 + 16);
+            r.s_ld_seg = layers[0].ksteps() * 32 + 16;
             r.s_ld_hid = ldh;
             const int x_bytes = 3 * bm * r.s_ld_seg * 2, h_bytes = 3 * bm * ldh * 2;
             r.s_buf1 = 0;

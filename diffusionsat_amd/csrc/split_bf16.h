@@ -9,9 +9,12 @@
 // rounding.  Measured against fp64 on the clause layers' shapes (tools/split_bf16_probe.hip): max error / sum|xw|
 // 1.55e-7 for the six-product form, 1.69e-7 for v_mfma_f32_16x16x4_f32 -- and 2.3-2.6x fewer cycles.
 //
-// Operand images: activations live in LDS as three planes of bf16 [rows][ld] (ld = K + 8 elements: a lane's
-// ds_read_b128 of row l&15, k = 32s + 8(l>>4) .. +7 is conflict-free); weights come from HBM/L2 as
-// [tile][k-step][plane][lane] 16-byte fragments (dsat_api.hip packs them), straight into registers.
+// Operand images: activations live in LDS as three planes of bf16 [rows][ld] with ld = K + 16 elements, i.e. a row
+// stride of 32 bytes mod 64: a lane's ds_read_b128 (row l&15, k = 32s + 8(l>>4) .. +7) has the byte pattern of
+// fused_common.h's fp32 fragments, and the hardware serves it eight rows of two k-groups at a time -- with K + 8
+// (16 bytes mod 64) rows r, k-group 1 and r + 1, k-group 0 share banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+// was 0.46 then).  Weights come from HBM/L2 as [tile][k-step][plane][lane] 16-byte fragments (dsat_api.hip packs
+// them), straight into registers.
 // As in fused_common.h the weight fragment is the MFMA's A operand, so a lane ends up with four consecutive
 // output columns of row l&15.
 #pragma once

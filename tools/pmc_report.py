@@ -18,6 +18,7 @@ import statistics
 import sys
 
 KERNELS = {"round_p1_kernel": "round_p1", "round_p2_kernel": "round_p2", "round_p3_kernel": "round_p3",
+           "round_p2s_kernel": "round_p2", "round_p3s_kernel": "round_p3",   # the split-product forms of the same tiles
            "heavy_gather_kernel": "heavy_row_gather", "segsum2_kernel": "pairnorm_segsum2",
            "select_sat_kernel": "select_sat", "aux_kernel": "aux"}
 
