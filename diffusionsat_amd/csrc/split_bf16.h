@@ -54,43 +54,6 @@ __device__ __forceinline__ void split_st4(unsigned short* planes, int plane, int
     *reinterpret_cast<uint2*>(planes + 2 * plane + off) = make_uint2(l0, l1);
 }
 
-// The three weight fragments of one (tile, k-step), one step ahead of their use.
-struct SplitW { uint4 h, m, l; };
-__device__ __forceinline__ SplitW split_wload(const uint4* __restrict__ wp, int step) {
-    const uint4* p = wp + (size_t)step * 192;   // 3 planes x 64 lanes
-    SplitW w;
-    w.h = p[0]; w.m = p[64]; w.l = p[128];
-    return w;
-}
-
-// k-steps [s0, s1) of one column tile for NRB row blocks.  `wp`: the lane's fragment of (tile, step 0, plane 0);
-// `w`: fragments of step s0, already requested; on return those of step min(s1, stot - 1).  `px`: the lane's
-// element (row l&15 of the first row block, k = 8(l>>4)) of plane 0 in a buffer whose column 0 is k-step `sbuf0`.
-template <int NRB>
-__device__ __forceinline__ void split_ksteps(const uint4* __restrict__ wp, int s0, int s1, int stot, SplitW& w,
-                                             const unsigned short* px, int plane, int ld, int sbuf0,
-                                             sf32x4 (&acc)[NRB]) {
-    for (int s = s0; s < s1; ++s) {
-        const SplitW nx = split_wload(wp, s + 1 < stot ? s + 1 : s);
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&w.h), wm = *reinterpret_cast<const bf16x8*>(&w.m),
-                     wl = *reinterpret_cast<const bf16x8*>(&w.l);
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-            const unsigned short* p = px + rb * 16 * ld + (s - sbuf0) * 32;
-            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(p);
-            const bf16x8 xm = *reinterpret_cast<const bf16x8*>(p + plane);
-            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(p + 2 * plane);
-            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[rb], 0, 0, 0);
-        }
-        w = nx;
-    }
-}
-
 // The weight ring.  Plain loads one step ahead are enough where four row blocks share a fragment (P2: 384 MFMA
 // cycles per wave and k-step); a 16-row tile has 96 cycles of MFMA work per 3 KiB of weights, is bound by the
 // weight stream and needs several steps in flight -- and hipcc drains every load at a loop's back edge
