@@ -95,7 +95,7 @@ def spawn_ranks(n_ranks):
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(instances, ws, rounds, nodes):
+def cpu_baseline(instances, ws, rounds, nodes, gpu_step=None):
     """CPU restatement (oracle/querysat_torch.py: PyTorch-CPU fp32, TensorFlow being unavailable) timed
     on this host as SURVEY.md §8d prescribes: 1 thread and all host cores, 1 warm-up then the median
     of 3; plus the fastest thread count of a short probe (sparse products of a 20k-node batch stop
@@ -132,8 +132,18 @@ def cpu_baseline(instances, ws, rounds, nodes):
             probe[t] = steps_per_s(t, reps=1, nr=min(2, rs))["value"]
     best_t = max(probe, key=probe.get)
     one, allc, best = steps_per_s(1), steps_per_s(ncpu), steps_per_s(best_t)
+    check = None
+    if gpu_step is not None:
+        # the baseline leg is also the checker: the HIP path's logits after the same `rs` rounds on the same
+        # injected draws against this restatement's (two fp32 computations with different summation orders)
+        torch.set_num_threads(best_t)
+        with torch.no_grad():
+            ref = QT.diffusion_step(tw, tb, 0.5, noisy, normal, labels, rs)["logits"].numpy()
+        got = gpu_step(0.5, noisy, normal, labels.astype(np.int32), rs)
+        check = {"rounds": rs, "max_abs_logit_diff_gpu_vs_cpu_port": float(np.abs(got - ref).max()),
+                 "max_abs_logit": float(np.abs(ref).max()), "tolerance_north_star": 1e-3}
     torch.set_num_threads(ncpu)
-    return {"value": best["value"], "unit": "denoising-steps/s", "cores": best_t, "kind": "port",
+    return {"value": best["value"], "unit": "denoising-steps/s", "cores": best_t, "kind": "port", "parity_check": check,
             "one_thread": one, "all_cores": allc, "best_of_probe": best, "host_cores": ncpu,
             "sample": "the first %d of the %d message-passing rounds of one denoising step of the same batch "
                       "(scaled to whole steps), PyTorch-CPU fp32 restatement, early exit off; 1 warm-up then "
@@ -470,7 +480,12 @@ def main():
             nflight = 1
             extra.clear()
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(instances, ws, args.rounds, batch.n_nodes)
+            def gpu_step(noise_scale, noisy, normal, labels, nr):
+                d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                o = sess.diffusion_step(noise_scale, d(noisy), d(normal), d(labels), rounds=nr, early_exit=False,
+                                        want_logits=True)
+                return o["logits"].cpu().numpy()
+            result["cpu_baseline"] = cpu_baseline(instances, ws, args.rounds, batch.n_nodes, gpu_step)
             result["cpu_baseline"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
     if dist is not None:
         dist.barrier()
