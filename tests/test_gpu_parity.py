@@ -435,7 +435,9 @@ def test_objects_are_bound_to_their_device(rt):
 
 @pytest.mark.parametrize("hidden,layers", [((100, 300, 150, 200, 64), (2, 2, 2, 3, 2)),
                                            ((153, 512, 204, 230, 128), (2, 4, 2, 2, 3)),
-                                           ((40, 64, 48, 72, 24), (3, 3, 3, 3, 2))])
+                                           ((40, 64, 48, 72, 24), (3, 3, 3, 3, 2)),
+                                           ((64, 96, 256, 256, 32), (2, 2, 2, 2, 2)),     # 16 column tiles, 2-layer update
+                                           ((64, 96, 17, 33, 32), (2, 2, 2, 3, 2))])      # narrow split layers
 def test_other_layer_counts_and_hidden_widths(rt, hidden, layers):
     """The reference constructor derives layer counts and hidden widths from its arguments
     (model/query_sat.py:101-122: msg_layers, the *_scale factors).  Anything but the released shapes leaves

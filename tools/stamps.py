@@ -65,7 +65,7 @@ def collect(config, rounds):
         rest = st[k, tiles[k]:]
         out[name] = rest[rest[:, 7] > 0]
     return out, {"config": config, "rounds": rounds, "n_vars": batch.n_vars, "n_clauses": batch.n_clauses,
-                 "n_graphs": batch.n_graphs}
+                 "n_graphs": batch.n_graphs, "split_mask": s.split_mask()}
 
 
 def table(stamps, meta):
@@ -78,6 +78,12 @@ def table(stamps, meta):
         ok = rt > 0
         ghz = float(np.median(tot[ok] / (rt[ok] * 10.0))) if ok.any() else float("nan")
         floor = MFMA_FLOOR[k]
+        mask = int(meta.get("split_mask", 0))
+        # split-product tiles (csrc/split_bf16.h): six 16-cycle bf16 MFMAs per 32 k-values, busiest SIMD
+        if k == "round_p2" and mask & 1:
+            floor = (13 * 12 + 16 * 7) * 6 * 16
+        if k == "round_p3" and mask & 2:
+            floor = (4 * 17 + 4 * 8 + 2 * 8) * 6 * 16
         kk = {"tiles": int(t.shape[0]), "cycles_per_tile_median": float(np.median(tot)),
               "cycles_per_tile_max": float(tot.max()), "clock_ghz_median": ghz,
               "us_per_tile_median": float(np.median(tot)) / (ghz * 1e3) if ghz == ghz else None,
