@@ -469,6 +469,8 @@ def main():
             s2.set_graph_replay(not args.eager)
             extra.append((s2, torch.cuda.Stream(device=dev)))
             nflight = 2
+            sess.set_throughput(True)    # several batches in flight: CU-cycles count, not one batch's latency
+            s2.set_throughput(True)
             run(4, seed=5)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -479,6 +481,7 @@ def main():
                                          "unit": "denoising-steps/s", "ms_per_step": 1e3 * el2 / args.steps}
             nflight = 1
             extra.clear()
+            sess.set_throughput(False)
         if world == 1 and not args.no_cpu_baseline:
             def gpu_step(noise_scale, noisy, normal, labels, nr):
                 d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)

@@ -78,6 +78,7 @@ SIGNATURES = {
     "dsat_op_is_graph_sat": (C.c_int, [_vp, _vp, _vp, _vp]),
     "dsat_session_packed_bytes": (_i64, [_vp, _vp]),
     "dsat_session_split_mask": (_i32, [_vp]),
+    "dsat_session_set_throughput": (C.c_int, [_vp, _i32]),
     "dsat_op_pack_assignment": (C.c_int, [_vp, _vp, _vp, _vp]),
     "dsat_op_rng": (C.c_int, [_vp, _u64, _u32, _i32, _vp, _vp, _vp, _vp]),
     "dsat_session_set_profile": (C.c_int, [_vp, _i32]),

@@ -678,6 +678,10 @@ struct dsat_session {
     // P1 role B: 64-row tile records; 0 blocks = the 16-row tiles run the output / query pair themselves
     std::vector<int32_t> h_vmeta4;
     int32_t* vmeta4 = nullptr;
+    size_t vmeta2_at = 0;   // offset (int32) of the 32-row records inside vmeta4
+    int p1_a2 = 0;          // P1 role A runs on 32-row tiles with split products (role_a2)
+    int p1_a2_ok = 0;       // ... is possible for this session (shapes, LDS, role B present)
+    int p1_a2_env = -1;     // DSAT_P1_A2: 0 never, 1 always, -1 (unset) by batch size / dsat_session_set_throughput
     int pair_blocks = 0;
     // select/SAT workgroups {graph, part, parts, 0}
     std::vector<int32_t> h_sel_tab;
@@ -935,6 +939,22 @@ static bool plan_round(dsat_session* s) {
         const bool fits = r.b_off_mean + mean_floats <= LDS;
         const bool shapes = ROUND_NWAVES == 16 && r.mq4.static_id == CHAIN_11 && r.mout4.static_id == CHAIN_11;
         s->pair_blocks = (fits && shapes && getenv("DSAT_NO_PAIRB") == nullptr) ? (g->N + 63) / 64 : 0;
+        // role A on 32-row tiles with lit_mlp as split products (kernels_round.hip, role_a2): the released
+        // 137 -> 512 -> 512 -> 256 shape, role B present (it then covers every 64-row group)
+        const auto& lit = w->mlp[DSAT_MLP_LIT];
+        const char* sw2 = getenv("DSAT_P1_A2");
+        s->p1_a2_ok = ROUND_NWAVES == 16 && s->pair_blocks != 0 && lit.size() == 3 && lit[0].kpad == F + AUX_W &&
+                      r.mlit.L[0].ntiles == 32 && r.mlit.L[1].ntiles == 32 && r.mlit.L[2].ntiles == 16 &&
+                      lit[1].kpad == 512 && lit[2].kpad == 512 && LDS * 4 >= 154112;
+        s->p1_a2_env = sw2 == nullptr ? -1 : (sw2[0] == '0' ? 0 : 1);
+        // Twice the rows per CU-cycle, but no shorter for a batch whose 16-row tiles all have a CU of their own
+        // (config 2: 194 + 49 workgroups; and the bf16 pipe's power costs the rest of the round 3 % of its clock):
+        // by default only for batches of more than one wave of workgroups, or when the caller asks for throughput
+        const bool large = (g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + s->pair_blocks > 256;
+        s->p1_a2 = s->p1_a2_ok && (s->p1_a2_env == 1 || (s->p1_a2_env == -1 && large));
+        r.vmeta2 = s->vmeta4 + s->vmeta2_at;
+        for (int l = 0; l < 3 && l < (int)lit.size(); ++l) r.a2_ws[l] = reinterpret_cast<const uint4*>(lit[l].ws);
+        if (getenv("DSAT_DEBUG_PLAN") != nullptr) fprintf(stderr, "[dsat] P1 role A on 32-row split tiles: %d\n", s->p1_a2);
     }
     {   // P2: [X BMx392 | A | (B) | mean]
         RoundArgs& r = s->ra2;
@@ -1136,6 +1156,11 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         {   // 64-row records for P1's role B (graphs, first graph's rows / segments; no CSR ranges, no segment base)
             std::vector<int32_t> none((size_t)(g->N + 63) / 64 + 1, 0), zero_rp(2 * (size_t)g->N + 1, 0);
             build_tile_meta(g->h_var_seg, g->N, 64, none, s->h_vgseg, zero_rp.data(), -1, s->h_vmeta4);
+            // ... and 32-row records for role A on 32-row tiles, behind them in the same table
+            std::vector<int32_t> none2((size_t)(g->N + 31) / 32 + 1, 0), meta2;
+            build_tile_meta(g->h_var_seg, g->N, 32, none2, s->h_vgseg, zero_rp.data(), -1, meta2);
+            s->vmeta2_at = s->h_vmeta4.size();
+            s->h_vmeta4.insert(s->h_vmeta4.end(), meta2.begin(), meta2.end());
         }
         const int32_t* crp = g->h_c_rowptr.data();
         if (g->max_clause_len > s->heavy_t) {   // heavy clauses: the mirror image of the heavy literal rows
@@ -1654,12 +1679,15 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         // output half alone
         a1.pair_blocks = 0;
         a1.pair_first = 0;
-        if (!a1.tail && s->pair_blocks != 0) {
+        a1.a2_tiles = s->p1_a2 ? (actN + 31) / 32 : 0;
+        if (s->p1_a2) {                       // 32-row A tiles: role B covers every group, in the tail launch too
+            a1.pair_blocks = (actN + 63) / 64;
+        } else if (!a1.tail && s->pair_blocks != 0) {
             if (r == 0 || pb_blocks < 0) plan_pair_blocks(actN, &pb_first, &pb_blocks);
             a1.pair_blocks = pb_blocks;
             a1.pair_first = pb_first;
         }
-        const int free_cus = 256 - vtiles - a1.pair_blocks;
+        const int free_cus = 256 - (s->p1_a2 ? a1.a2_tiles : vtiles) - a1.pair_blocks;
         const int cn = (r > 0 && r < rounds && actC > 0 && free_cus >= 8 && !s->no_cn) ? free_cus : 0;
         a1.cn_blocks = cn;
         float* vbuf[2] = {s->V, s->Vlog};   // carried state, double-buffered by round (Vlog is free on this path)
@@ -1742,7 +1770,7 @@ static int run_step(dsat_session* s, hipStream_t st, int rounds, int early_exit,
         DSAT_HIP(hipGetLastError());
         return DSAT_OK;
     }
-    auto key = std::make_tuple(rounds, early_exit, mode, s->use_fused);
+    auto key = std::make_tuple(rounds, early_exit, mode, s->use_fused + 2 * s->p1_a2);
     auto it = s->graphs.find(key);
     if (it == s->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -2231,9 +2259,18 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t* __restric
 }
 }  // namespace dsat
 
+extern "C" int dsat_session_set_throughput(dsat_session* s, int32_t enable) {
+    DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_throughput: null session");
+    if (s->p1_a2_env == -1) {
+        const bool large = (s->g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + s->pair_blocks > 256;
+        s->p1_a2 = s->p1_a2_ok && (enable != 0 || large);
+    }
+    return DSAT_OK;
+}
+
 extern "C" int32_t dsat_session_split_mask(const dsat_session* s) {
     if (s == nullptr || !s->use_fused) return 0;
-    return (s->p2_split ? 1 : 0) | (s->p3_split ? 2 : 0);
+    return (s->p2_split ? 1 : 0) | (s->p3_split ? 2 : 0) | (s->p1_a2 ? 4 : 0);
 }
 
 extern "C" int64_t dsat_session_packed_bytes(const dsat_session* s, int32_t* offsets_out) {

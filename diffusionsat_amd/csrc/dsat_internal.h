@@ -258,6 +258,11 @@ struct RoundArgs {
     // weights
     ChainSpec mq, mlit, mcl, mupd, mout;
     ChainSpec mq4, mout4;  // variables_query / variables_output blocked for 64-row tiles (P1 role B)
+    // P1 role A on 32-row tiles with lit_mlp's products formed from bf16 slices (kernels_round.hip, role_a2):
+    // a2_tiles > 0 replaces the 16-row A tiles; role B then covers every 64-row group
+    const int32_t* vmeta2;  // 32-row records (as vmeta4)
+    int a2_tiles;
+    const uint4* a2_ws[3];  // lit_mlp's three layers as bf16 slices
     // P2 / P3 with fp32 products formed from bf16 slices (round_p2s_kernel, round_p3s_kernel, split_bf16.h): per
     // layer the weights as three bf16 planes in fragment order, k-steps of 32 and column tiles; LDS plan in
     // BYTES / bf16 elements (P3: s_buf1 = the input planes, s_buf2 = hidden A then hidden B)

@@ -465,6 +465,106 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
     }
 }
 
+// ------------------------------------------------------------------------------------- P1, role A on 32 rows
+// lit_mlp (137 -> 512 -> 512 -> 256, query_sat.py:252-254) with fp32 products from bf16 slices (split_bf16.h) pays
+// only with more rows per weight fragment than a 16-row tile has (a 16-row tile as slices is bound by its weight
+// stream, §4.7), and two 512-wide hidden tiles of 32 rows (100 KB each as three planes) do not fit LDS.  So layer 1
+// is computed in two column halves and layer 2 accumulates over the matching halves of its K range:
+//   L0 (two passes of 16 column tiles) -> h1 | L1 cols 0-255 -> h2 | L2 k 0-255 | L1 cols 256-511 -> h2 | L2 k 256-511
+// LDS: h1 [3][32][528] (first the fp32 PairNorm rows) + max(v1 planes [3][32][176], h2 half [3][32][272]) = 150 KB.
+// 66 k cycles per 32 rows (tools/lit32_probe.hip) against 68 k per 16 rows on the fp32 MFMA.
+#if DSAT_ROUND_NWAVES == 16
+__device__ __forceinline__ void role_a2(const RoundArgs& a, int tile, const TileMetaDev& tm, float* smem, int tid) {
+    constexpr int BM = 32, PD = DSAT_SPLIT_PD4;
+    constexpr int KS0 = (F + AUX_W + 31) / 32, LDX = KS0 * 32 + 16, HID = 512, LD1 = HID + 16, LD2 = HID / 2 + 16;
+    constexpr int KS1 = HID / 32, KS2 = HID / 32;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int N = a.N, NL = a.NL;
+    const int tile_lo = tile * BM;
+    unsigned short* h1 = reinterpret_cast<unsigned short*>(smem);           // [3][32][LD1]
+    unsigned short* r2 = h1 + 3 * BM * LD1;                                 // v1 planes, then the h2 half
+    float* sMean = reinterpret_cast<float*>(r2 + 3 * BM * LD2);             // F floats
+    float* sState = smem;                                                   // fp32 rows [32][ldS] inside h1's space
+    constexpr int ldS = F + AUX_W + 8;
+    float* sPart = sState + BM * ldS;                                       // NT / F rows of F floats
+    DSAT_STAMP_RT_BEGIN(a);
+    DSAT_STAMP(a, 0);
+    if (tid < BM) {   // aux columns of v1 for this round
+        const int n = tile_lo + tid;
+        load_aux_row(sState + tid * ldS + F, a.aux, n, N, a.round, n < N && !a.tail);
+    }
+    pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, a.V_out,
+                      a.round == 0, sState, ldS, nullptr, 0, sMean, sPart, F, tid);
+    DSAT_STAMP(a, 1);
+    DSAT_STAMP(a, 2);
+    DSAT_STAMP(a, 3);
+    if (a.tail) {   // the tail launch only finishes the PairNorm (role B makes the logits)
+        DSAT_STAMP(a, 4);
+        DSAT_STAMP_RT_END(a);
+        return;
+    }
+    // v1 = [state | aux | zeros up to the last k-step] as slices
+    for (int i = tid; i < BM * (KS0 * 8); i += NT) {
+        const int r = i / (KS0 * 8), c = 4 * (i % (KS0 * 8));
+        const float4 v = c < F + AUX_W ? ld4(sState + r * ldS + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        split_st4(r2, BM * LDX, r * LDX + c, v);
+    }
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff = (unsigned)lane * 16u;
+    const int col4 = 4 * (lane >> 4), row = lane & 15;
+    auto wb = [&](int l, int t, int ks) { return reinterpret_cast<const float4*>(a.a2_ws[l]) + ((size_t)t * ks * 3) * 64; };
+    auto leaky = [](f32x4 acc, float4 b) { return bias_act(acc, b, 1); };
+    float4 b0a = *reinterpret_cast<const float4*>(a.mlit.L[0].bias + wv * 16 + col4);
+    float4 b0b = *reinterpret_cast<const float4*>(a.mlit.L[0].bias + (wv + 16) * 16 + col4);
+    float4 b1a = *reinterpret_cast<const float4*>(a.mlit.L[1].bias + wv * 16 + col4);
+    float4 b1b = *reinterpret_cast<const float4*>(a.mlit.L[1].bias + (wv + 16) * 16 + col4);
+    float4 b2 = *reinterpret_cast<const float4*>(a.mlit.L[2].bias + wv * 16 + col4);
+    asm volatile("" : "+v"(b0a.x), "+v"(b0a.y), "+v"(b0a.z), "+v"(b0a.w), "+v"(b0b.x), "+v"(b0b.y), "+v"(b0b.z), "+v"(b0b.w));
+    asm volatile("" : "+v"(b1a.x), "+v"(b1a.y), "+v"(b1a.z), "+v"(b1a.w), "+v"(b1b.x), "+v"(b1b.y), "+v"(b1b.z), "+v"(b1b.w));
+    asm volatile("" : "+v"(b2.x), "+v"(b2.y), "+v"(b2.z), "+v"(b2.w));
+    const unsigned short* xin = r2 + row * LDX + 8 * (lane >> 4);
+    const unsigned short* h1in = h1 + row * LD1 + 8 * (lane >> 4);
+    const unsigned short* h2in = r2 + row * LD2 + 8 * (lane >> 4);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a0[2] = {z, z}, a0b[2] = {z, z}, a1[2] = {z, z}, a1b[2] = {z, z}, a2[2] = {z, z};
+    // L0, two passes; the first barrier also ends the reads of the fp32 rows h1 is about to overwrite
+    split_layer<2, PD>(voff, wb(0, wv, KS0), KS0, xin, BM * LDX, LDX, [] {}, a0);
+    auto ep0a = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) split_st4(h1, BM * LD1, (rb * 16 + row) * LD1 + wv * 16 + col4, leaky(a0[rb], b0a));
+    };
+    split_layer<2, PD, false>(voff, wb(0, wv + 16, KS0), KS0, xin, BM * LDX, LDX, ep0a, a0b);
+    auto ep0b = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) split_st4(h1, BM * LD1, (rb * 16 + row) * LD1 + (wv + 16) * 16 + col4, leaky(a0b[rb], b0b));
+    };
+    split_layer<2, PD>(voff, wb(1, wv, KS1), KS1, h1in, BM * LD1, LD1, ep0b, a1);            // L1 columns 0..255
+    auto ep1a = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) split_st4(r2, BM * LD2, (rb * 16 + row) * LD2 + wv * 16 + col4, leaky(a1[rb], b1a));
+    };
+    split_layer<2, PD>(voff, wb(2, wv, KS2), KS2 / 2, h2in, BM * LD2, LD2, ep1a, a2);         // L2, k 0..255
+    split_layer<2, PD, false>(voff, wb(1, wv + 16, KS1), KS1, h1in, BM * LD1, LD1, [] {}, a1b);   // L1 columns 256..511
+    auto ep1b = [&]() {
+        lds_barrier();   // every wave is done with the first half of h2
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) split_st4(r2, BM * LD2, (rb * 16 + row) * LD2 + wv * 16 + col4, leaky(a1b[rb], b1b));
+    };
+    split_layer<2, PD>(voff, wb(2, wv, KS2) + (size_t)(KS2 / 2) * 192, KS2 / 2, h2in, BM * LD2, LD2, ep1b, a2);   // L2, k 256..511
+    // R6: literals = [lit_mlp(v1)[:, :128] ; [:, 128:]]
+    float* lits = a.lits;
+    const int col = wv * 16 + col4;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        int n = tile_lo + rb * 16 + row;
+        NO_HOIST(n);
+        if (n < N) stg4(lits + ((size_t)(col < F ? n : NL + n)) * F + (col & (F - 1)), bias_act(a2[rb], b2, 0));
+    }
+    DSAT_STAMP(a, 4);
+    DSAT_STAMP_RT_END(a);
+}
+#endif
+
 // ------------------------------------------------------------------------------------- P1
 // Three roles in one grid:
 //   A  blocks [0, vtiles): 16-row variable tiles -- PairNorm (R13, writes the carried state), lit_mlp (R6);
@@ -483,7 +583,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
     constexpr int BM = ROUND_BM_VAR;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.N, NL = a.NL;
-    const int vtiles = (N + BM - 1) / BM;
+    const int vtiles = a.a2_tiles > 0 ? a.a2_tiles : (N + BM - 1) / BM;   // role A: 16-row tiles, or 32-row ones (role_a2)
     const int b = blockIdx.x;
     const bool roleA = b < vtiles, roleB = !roleA && b < vtiles + a.pair_blocks;
     // role B covers the 64-row groups [pair_first, pair_first + pair_blocks): normally all of them; on grids of
@@ -492,8 +592,14 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
     const int tile = roleA ? xcd_tile(b, vtiles) : (roleB ? a.pair_first + (b - vtiles) : 0);
     // the early-exit flag and the tile record are requested together: one memory latency, not two
     const int done = a.check_done ? a.ctl->done : 0;
-    const TileMetaDev tm = load_meta(roleB ? a.vmeta4 : a.vmeta, tile);
+    const TileMetaDev tm = load_meta(roleB ? a.vmeta4 : (a.a2_tiles > 0 ? a.vmeta2 : a.vmeta), tile);
     if (both_arrived(done, tm) != 0) return;
+#if DSAT_ROUND_NWAVES == 16
+    if (roleA && a.a2_tiles > 0) {
+        role_a2(a, tile, tm, smem, tid);
+        return;
+    }
+#endif
     if (!roleA && !roleB) {
         DSAT_STAMP_RT_BEGIN(a);
         DSAT_STAMP(a, 0);
@@ -521,7 +627,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
         DSAT_STAMP(a, 0);
         if (tid < BM4) {
             const int n = tile_lo + tid;
-            load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N);
+            load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N && !a.tail);
         }
         pairnorm_tile<BM4>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, nullptr,
                            a.round == 0, sX, ldx, sVlog, ldv, sMean, sMean + F, F, tid);
@@ -552,7 +658,8 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
         DSAT_STAMP(a, 1);
         if (a.round > 0) run_chain<4>(a.mout4, sVlog, ldv, sA, a.b_ld_a, sB, a.b_ld_b, wave, lane, store_logits);
         DSAT_STAMP(a, 2);
-        run_chain<4>(a.mq4, sX, ldx, sB, a.b_ld_b, sA, a.b_ld_a, wave, lane, store_query);
+        // (the tail launch -- role B runs in it when role A is on 32-row tiles -- is the output half alone)
+        if (!a.tail) run_chain<4>(a.mq4, sX, ldx, sB, a.b_ld_b, sA, a.b_ld_a, wave, lane, store_query);
         DSAT_STAMP(a, 3);
         DSAT_STAMP(a, 4);
         DSAT_STAMP_RT_END(a);
@@ -1681,7 +1788,7 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
 }  // namespace
 
 hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st) {
-    const int tiles = (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + a.pair_blocks + a.cn_blocks;
+    const int tiles = (a.a2_tiles > 0 ? a.a2_tiles : (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR) + a.pair_blocks + a.cn_blocks;
     hipLaunchKernelGGL(round_p1_kernel, dim3(tiles), dim3(NT), 0, st, a);
     return hipGetLastError();
 }

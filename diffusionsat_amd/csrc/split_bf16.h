@@ -197,18 +197,19 @@ __device__ __forceinline__ void split_layer_segments(unsigned voff, const float4
     }
 }
 
-template <int NRB, int PD, typename Prep>
+// BARRIER = false: the input is already published (prep() then only has to run somewhere before the k-steps).
+template <int NRB, int PD, bool BARRIER = true, typename Prep>
 __device__ __forceinline__ void split_layer(unsigned voff, const float4* __restrict__ wbase, int stot,
                                             const unsigned short* px, int plane, int ld, Prep&& prep,
                                             sf32x4 (&acc)[NRB > 0 ? NRB : 1]) {
     if constexpr (NRB == 0) {
         prep();
-        lds_barrier();
+        if (BARRIER) lds_barrier();
     } else {
         SplitSlot ring[PD];
         split_prime<PD>(ring, voff, wbase, stot);
         prep();
-        lds_barrier();
+        if (BARRIER) lds_barrier();
         const int main = stot / PD * PD;
         split_ring_steps<NRB, PD>(ring, voff, wbase, 0, main, stot, px, plane, ld, 0, acc);
         split_ring_tail<NRB, PD>(ring, main, stot, px, plane, ld, 0, acc);

@@ -194,6 +194,8 @@ class DiffusionSampler:
             if self.retire_solved:
                 sess.set_retire(True)
             slots.append((sess, torch.cuda.Stream(device=self.model.device)))
+        for sess, _ in slots[:k]:
+            sess.set_throughput(k > 1)       # several batches in flight: CU-cycles count, not one batch's latency
         return slots[:k]
 
     def _launch(self, it: int, copies: int, seed: int):

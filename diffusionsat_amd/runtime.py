@@ -374,6 +374,10 @@ class Session:
         the bf16 matrix pipe (``dsat_session_split_mask``)."""
         return int(_lib.load().dsat_session_split_mask(self.handle))
 
+    def set_throughput(self, enable: bool):
+        """Several batches in flight on this GPU: prefer CU-cycles to one batch's latency (``dsat_session_set_throughput``)."""
+        _lib.check(_lib.load().dsat_session_set_throughput(self.handle, int(enable)))
+
     def set_profile(self, enable: bool):
         _lib.check(_lib.load().dsat_session_set_profile(self.handle, int(enable)))
 

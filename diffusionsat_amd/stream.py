@@ -63,6 +63,8 @@ class StreamSampler:
                     except Exception:
                         graph.close()
                         raise
+                    if len(self.slots) > 1:
+                        sess.set_throughput(True)    # batches overlap on the GPU: CU-cycles count
                 break
             except _lib.DsatError as ex:
                 if slot.arena is None or "arena too small" not in str(ex):

@@ -272,11 +272,19 @@ int dsat_session_read_stamps(dsat_session* s, int64_t* out, int64_t n);
 int dsat_session_profile(dsat_session* s, int32_t cap, const char** names, double* us_out,
                          int64_t* launches_out);
 /* Which arithmetic the round kernels of this session run their MLPs (model/mlp.py:42-50) in: bit 0 set = the
- * clause tile (P2), bit 1 set = the variable-update tile (P3) form every fp32 product from three bf16 slices
+ * clause tile (P2), bit 1 set = the variable-update tile (P3), bit 2 set = lit_mlp of P1 (on 32-row tiles) form
+ * every fp32 product from three bf16 slices
  * per operand on the bf16 matrix pipe (six slice products, fp32 accumulation: fp32-level error, see
  * diffusionsat_amd/csrc/split_bf16.h); clear = v_mfma_f32_16x16x4_f32.  The environment variables
  * DSAT_P2_SPLIT=0 / DSAT_P3_SPLIT=0 at session creation select the fp32-MFMA form. */
 int32_t dsat_session_split_mask(const dsat_session* s);
+/* Several batches in flight on one GPU (a stream of batches, satuniformity/DiffusionSampler.py:283-307 with n > one
+ * batch; data/dimac.py:267-293): prefer CU-cycles over the latency of one batch.  Today this runs lit_mlp
+ * (model/query_sat.py:252-254) on 32-row tiles with split products also for batches small enough to give every
+ * 16-row tile a CU of its own (bit 2 of dsat_session_split_mask; batches of more than one wave of workgroups get
+ * it anyway; DSAT_P1_A2=0/1 in the environment at session creation overrides both).  Results are the same to fp32
+ * rounding (not bitwise: another summation order).  Takes effect from the next step. */
+int dsat_session_set_throughput(dsat_session* s, int32_t enable);
 
 /* Debug tap (parity tests of the kernels that are actually hot): the intermediates of message-passing
  * round `round` of the NEXT dsat_diffusion_step call, copied out of the running kernels' buffers (or,

@@ -500,8 +500,8 @@ def _fuzz_instances(seed):
 @pytest.mark.parametrize("seed", range(8))
 def test_random_batch_structures_match_oracle(rt, seed):
     """Structure fuzz (the reference batches whatever the dataset yields, data/k_sat.py:60-117: any mix of
-    sizes): 3 rounds of logits against the oracle on the three kernel forms (fused tiles with split products,
-    fused tiles on the fp32 MFMA, per-layer kernels), then is_graph_sat and the packed bits."""
+    sizes): 3 rounds of logits against the oracle on the four kernel forms (fused tiles with split products,
+    the same with lit_mlp on 32-row split tiles, fused tiles on the fp32 MFMA, per-layer kernels), then is_graph_sat and the packed bits."""
     insts = _fuzz_instances(seed)
     from diffusionsat_amd.batch import make_batch
     batch = make_batch(insts)
@@ -514,7 +514,7 @@ def test_random_batch_structures_match_oracle(rt, seed):
                            dt=np.float32, trace=("logits",))
     g = rt.Graph(batch)
     w = rt.Weights(ws)
-    for env in ({}, {"DSAT_P2_SPLIT": "0", "DSAT_P3_SPLIT": "0"}, {"DSAT_FUSED": "0"}):
+    for env in ({}, {"DSAT_P1_A2": "1"}, {"DSAT_P2_SPLIT": "0", "DSAT_P3_SPLIT": "0", "DSAT_P1_A2": "0"}, {"DSAT_FUSED": "0"}):
         os.environ.update(env)
         try:
             s = rt.Session(g, w, max_rounds=rounds)
