@@ -334,6 +334,7 @@ def main():
             # f32 in, f32 out, f32 accumulation everywhere; where arithmetic_note says so, an MLP's f32 products are
             # formed exactly-to-f32-rounding from bf16 slices (same tolerances against the f64 oracle as the f32 MFMA)
             "arithmetic_note": ("clause_mlp" if sess.split_mask() & 1 else "") + (" update_gate" if sess.split_mask() & 2 else "")
+                               + (" lit_mlp" if sess.split_mask() & 4 else "")
                                + (": fp32 products as six bf16-slice products on v_mfma_f32_16x16x32_bf16 (csrc/split_bf16.h); "
                                   "all else v_mfma_f32_16x16x4_f32" if sess.split_mask() else "v_mfma_f32_16x16x4_f32 everywhere"),
             "solved_fraction": solved_fraction,
@@ -390,11 +391,18 @@ def main():
                     ach = fl / (us * 1e-6) / 1e12
                     sp = split.get(k, False)
                     peak = PEAK_SPLIT_F32EQ_TFLOPS if sp else PEAK_MFMA_F32_TFLOPS
+                    a2 = k == "round_p1_var_query_lit" and bool(mask & 4)
+                    if a2:   # lit_mlp as split products on 32-row tiles, the output / query MLPs on the fp32 MFMA:
+                        # the ceiling is the time-weighted mix of the two pipes' peaks (MACs per row: SURVEY.md §8d)
+                        peak = (463_360 + 40_545 + 17_408) / (463_360 / PEAK_SPLIT_F32EQ_TFLOPS + (40_545 + 17_408) / PEAK_MFMA_F32_TFLOPS)
                     roofs[k] = {"bound": "mfma", "kernel": kern_name[k].replace("_kernel<4>", "s_kernel").replace("p3_kernel", "p3s_kernel") if sp else kern_name[k],
                                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                 "pipe": ("v_mfma_f32_16x16x32_bf16, six bf16-slice products per fp32 product: achieved = "
                                          "algorithmic fp32 flops / time, peak = dense bf16 MFMA peak %.0f / 6"
-                                         % PEAK_MFMA_BF16_TFLOPS) if sp else "v_mfma_f32_16x16x4_f32",
+                                         % PEAK_MFMA_BF16_TFLOPS) if sp else
+                                        ("lit_mlp: v_mfma_f32_16x16x32_bf16 x6 per fp32 product on 32-row tiles; output / query MLPs: "
+                                         "v_mfma_f32_16x16x4_f32; peak = the two pipes' ceilings weighted by their flops") if a2
+                                        else "v_mfma_f32_16x16x4_f32",
                                 "traffic": traffic.get(k) if default_cfg2 else None,
                                 "avg_launch_us": us,
                                 "launches_per_step": prof[k]["launches"] / steps_prof,
