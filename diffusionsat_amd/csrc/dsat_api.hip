@@ -931,14 +931,38 @@ static bool plan_round(dsat_session* s) {
         r.vmeta4 = s->vmeta4;
         r.b_ld_a = max_hidden_pad(w->mlp[DSAT_MLP_VARIABLES_OUTPUT]) + 8;
         r.b_ld_b = max_hidden_pad(w->mlp[DSAT_MLP_VARIABLES_QUERY]) + 8;
+        // [X | B | Vlog | A | mean]: X and B adjacent, Vlog and A adjacent -- the split-product query chain reuses each
+        // pair as one region (kernels_round.hip, role B)
         r.b_off_x = 0;
-        r.b_off_vlog = 64 * r.ld_x;
+        r.b_off_b = 64 * r.ld_x;
+        r.b_off_vlog = r.b_off_b + 64 * r.b_ld_b;
         r.b_off_a = r.b_off_vlog + 64 * (F + 8);
-        r.b_off_b = r.b_off_a + 64 * r.b_ld_a;
-        r.b_off_mean = r.b_off_b + 64 * r.b_ld_b;
+        r.b_off_mean = r.b_off_a + 64 * r.b_ld_a;
         const bool fits = r.b_off_mean + mean_floats <= LDS;
         const bool shapes = ROUND_NWAVES == 16 && r.mq4.static_id == CHAIN_11 && r.mout4.static_id == CHAIN_11;
         s->pair_blocks = (fits && shapes && getenv("DSAT_NO_PAIRB") == nullptr) ? (g->N + 63) / 64 : 0;
+        {   // variables_query of role B with split products: v1 planes [3][64][K + 16] in Vlog | A, hidden planes in X | B
+            const auto& ql = w->mlp[DSAT_MLP_VARIABLES_QUERY];
+            const char* swb = getenv("DSAT_P1_BSPLIT");
+            if (s->pair_blocks != 0 && ql.size() == 2 && ql[0].kpad == F + AUX_W && r.mq4.L[0].ntiles <= ROUND_NWAVES &&
+                r.mq4.L[1].ntiles <= ROUND_NWAVES && !(swb != nullptr && swb[0] == '0')) {
+                const int ldp = ql[0].ksteps() * 32 + 16, ldq = ql[1].ksteps() * 32 + 16;
+                const int xp_bytes = 3 * 64 * ldp * 2, hp_bytes = 3 * 64 * ldq * 2;
+                if (xp_bytes <= 64 * ((F + 8) + r.b_ld_a) * 4 && hp_bytes <= 64 * (r.ld_x + r.b_ld_b) * 4 &&
+                    r.mq4.L[0].ntiles * 16 <= ql[1].ksteps() * 32) {
+                    r.s_ld_seg = ldp;
+                    r.s_ld_hid = ldq;
+                    for (int l = 0; l < 2; ++l) {
+                        r.sp_ws[l] = reinterpret_cast<const uint4*>(ql[l].ws);
+                        r.sp_ks[l] = ql[l].ksteps();
+                        r.sp_nt[l] = r.mq4.L[l].ntiles;
+                    }
+                    r.sp_layers = 2;
+                }
+            }
+            if (getenv("DSAT_DEBUG_PLAN") != nullptr)
+                fprintf(stderr, "[dsat] P1 role B query chain as split products: %d\n", r.sp_ws[0] != nullptr);
+        }
         // role A on 32-row tiles with lit_mlp as split products (kernels_round.hip, role_a2): the released
         // 137 -> 512 -> 512 -> 256 shape, role B present (it then covers every 64-row group)
         const auto& lit = w->mlp[DSAT_MLP_LIT];
@@ -2270,7 +2294,7 @@ extern "C" int dsat_session_set_throughput(dsat_session* s, int32_t enable) {
 
 extern "C" int32_t dsat_session_split_mask(const dsat_session* s) {
     if (s == nullptr || !s->use_fused) return 0;
-    return (s->p2_split ? 1 : 0) | (s->p3_split ? 2 : 0) | (s->p1_a2 ? 4 : 0);
+    return (s->p2_split ? 1 : 0) | (s->p3_split ? 2 : 0) | (s->p1_a2 ? 4 : 0) | (s->ra1.sp_ws[0] != nullptr && s->pair_blocks ? 8 : 0);
 }
 
 extern "C" int64_t dsat_session_packed_bytes(const dsat_session* s, int32_t* offsets_out) {

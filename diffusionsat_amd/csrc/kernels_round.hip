@@ -659,6 +659,26 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
         if (a.round > 0) run_chain<4>(a.mout4, sVlog, ldv, sA, a.b_ld_a, sB, a.b_ld_b, wave, lane, store_logits);
         DSAT_STAMP(a, 2);
         // (the tail launch -- role B runs in it when role A is on 32-row tiles -- is the output half alone)
+#if DSAT_ROUND_NWAVES == 16
+        if (!a.tail && a.sp_ws[0] != nullptr) {
+            // variables_query with split products (split_bf16.h): v1 as slices goes where the output chain's tiles were
+            // (sVlog | sA, dead now), the hidden planes over the fp32 v1 rows and the unused second buffer (sX | sB)
+            unsigned short* xp = reinterpret_cast<unsigned short*>(sVlog);
+            unsigned short* hp = reinterpret_cast<unsigned short*>(sX);
+            const int ldp = a.s_ld_seg;
+            for (int i = tid; i < BM4 * (ldp - 16) / 4; i += NT) {
+                const int r = i / ((ldp - 16) / 4), c = 4 * (i % ((ldp - 16) / 4));
+                const float4 v = c < F + AUX_W ? ld4(sX + r * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                split_st4(xp, BM4 * ldp, r * ldp + c, v);
+            }
+            SplitChain sc;
+            sc.nlayers = 2;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) sc.L[l] = SplitLayer{a.sp_ws[l < 2 ? l : 0], a.mq4.L[l < 2 ? l : 0].bias, a.sp_ks[l < 2 ? l : 0], a.sp_nt[l < 2 ? l : 0]};
+            const int wvu = __builtin_amdgcn_readfirstlane(wave);
+            split_chain<4, NT, DSAT_SPLIT_PD4>(sc, xp, ldp, hp, hp, a.s_ld_hid, wvu, lane, tid, store_query, [] {});
+        } else
+#endif
         if (!a.tail) run_chain<4>(a.mq4, sX, ldx, sB, a.b_ld_b, sA, a.b_ld_a, wave, lane, store_query);
         DSAT_STAMP(a, 3);
         DSAT_STAMP(a, 4);
