@@ -656,6 +656,7 @@ struct dsat_session {
     int p2_rb = 4;
     int p2_split = 0;   // P2 runs round_p2s_kernel (fp32 products from bf16 slices)
     int p3_split = 0;   // P3 runs round_p3s_kernel
+    int p3_bm = 16;     // ... on tiles of this many rows (the PairNorm segment tables follow it)
     float *sp = nullptr, *psum_v = nullptr, *psum_c = nullptr;
     int32_t *vmeta = nullptr, *vgseg = nullptr, *cmeta = nullptr, *cgseg = nullptr;
     std::vector<int32_t> h_vtile_seg, h_vgseg, h_ctile_seg, h_cgseg, h_vmeta, h_cmeta;
@@ -1062,18 +1063,26 @@ static bool plan_round(dsat_session* s) {
                       layers[0].kpad == 4 * F + AUX_W && !(sw != nullptr && sw[0] == '0');
         for (int l = 0; shapes && l < r.mupd.nlayers; ++l) shapes = r.mupd.L[l].ntiles <= ROUND_NWAVES;
         if (shapes) {
-            const int bm = ROUND_BM_VAR;
+            const int bm = s->p3_bm;
             int ldh = 48;
             for (size_t l = 1; l < layers.size(); ++l) ldh = std::max(ldh, layers[l].ksteps() * 32 + 16);
             r.s_ld_seg = layers[0].ksteps() * 32 + 16;
             r.s_ld_hid = ldh;
             const int x_bytes = 3 * bm * r.s_ld_seg * 2, h_bytes = 3 * bm * ldh * 2;
+            // 16 rows: [X | hA | hB | sums], the stage of the column sums over X, the CSR lists over hA and hB;
+            // 32 rows: [X = hB | hA | sums] (X is dead once layer 0 has run), the stage and the lists over hA
+            const bool wide = bm == 32;
+            r.p3_bm = bm;
             r.s_buf1 = 0;
             r.s_buf2 = x_bytes;
+            r.s_bufB = wide ? 0 : x_bytes + h_bytes;
+            r.s_stage = wide ? x_bytes : 0;
             r.s_idx = r.s_buf2;
-            r.s_idx_cap = (2 * h_bytes / 4 - 2 * (bm + 8)) / 2;
-            r.s_mean = r.s_buf2 + 2 * h_bytes;
-            if (r.s_mean + ROUND_NWAVES * 64 * 4 <= LDS * 4 && bm * (F + 8) * 4 <= x_bytes && r.s_idx_cap >= 256) {
+            r.s_idx_cap = ((wide ? 1 : 2) * h_bytes / 4 - 2 * (bm + 8)) / 2;
+            r.s_mean = r.s_buf2 + (wide ? 1 : 2) * h_bytes;
+            if (wide) r.vmeta = s->vmeta4 + s->vmeta2_at;
+            if (r.s_mean + ROUND_NWAVES * 64 * 4 <= LDS * 4 && bm * (F + 8) * 4 <= (wide ? h_bytes : x_bytes) &&
+                r.s_idx_cap >= 256) {
                 r.sp_layers = r.mupd.nlayers;
                 for (int l = 0; l < r.mupd.nlayers; ++l) {
                     r.sp_ws[l] = reinterpret_cast<const uint4*>(layers[l].ws);
@@ -1083,9 +1092,10 @@ static bool plan_round(dsat_session* s) {
                 s->p3_split = 1;
             }
         }
+        if (s->p3_bm == 32 && !s->p3_split) ok = false;   // the tables were built for 32-row producer tiles
         if (getenv("DSAT_DEBUG_PLAN") != nullptr)
-            fprintf(stderr, "[dsat] P3 split=%d (ldx %d ldh %d, hidden at %d, lists cap %d, sums at %d of %d bytes)\n",
-                    s->p3_split, r.s_ld_seg, r.s_ld_hid, r.s_buf2, r.s_idx_cap, r.s_mean, LDS * 4);
+            fprintf(stderr, "[dsat] P3 split=%d rows %d (ldx %d ldh %d, hidden at %d, lists cap %d, sums at %d of %d bytes)\n",
+                    s->p3_split, s->p3_bm, r.s_ld_seg, r.s_ld_hid, r.s_buf2, r.s_idx_cap, r.s_mean, LDS * 4);
     }
     return ok;
 }
@@ -1112,7 +1122,27 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
         for (; rb > 1; rb >>= 1)
             if (16 * rb * (3 * F + 8) + 16 * rb * (hid + 8) * (cl.size() > 2 ? 2 : 1) + ROUND_NWAVES * 64 <= ROUND_LDS_FLOATS) break;
         s->p2_rb = rb;
-        build_segments(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg);
+        {   // P3 as split products on 32-row tiles (half the weight stream per row, kernels_round.hip): decided here
+            // because the PairNorm segment tables follow the producer's tile size.  Batches of more than one wave of
+            // 16-row tiles only (a smaller batch gives every tile a CU of its own: nothing to save); DSAT_P3_BM forces.
+            const auto& up = w->mlp[DSAT_MLP_UPDATE_GATE];
+            const char* e32 = getenv("DSAT_P3_BM");
+            const char* esp = getenv("DSAT_P3_SPLIT");
+            bool shapes = ROUND_NWAVES == 16 && (up.size() == 2 || up.size() == 3) && up[0].kpad == 4 * F + AUX_W &&
+                          !(esp != nullptr && esp[0] == '0');
+            int ldh = 48;
+            for (size_t l = 0; shapes && l < up.size(); ++l) {
+                shapes = (up[l].out_dim + 15) / 16 <= ROUND_NWAVES;
+                if (l > 0) ldh = std::max(ldh, up[l].ksteps() * 32 + 16);
+            }
+            const int ldx = up[0].ksteps() * 32 + 16;
+            const bool fits = 3 * 32 * ldx * 2 + 3 * 32 * ldh * 2 + ROUND_NWAVES * 64 * 4 <= ROUND_LDS_FLOATS * 4 && ldh <= ldx &&
+                              32 * (F + 8) * 4 <= 3 * 32 * ldh * 2;
+            const bool large = (g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR > 256;
+            const int want = e32 != nullptr ? atoi(e32) : (large ? 32 : 16);
+            s->p3_bm = (shapes && fits && want == 32) ? 32 : ROUND_BM_VAR;
+        }
+        build_segments(g->h_var_seg, g->N, s->p3_bm, s->h_vtile_seg, s->h_vgseg);
         build_segments(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg);
         // level-2 PairNorm sums for graphs spread over many tiles
         auto level2 = [](const std::vector<int32_t>& gseg, std::vector<int32_t>& gseg2, std::vector<int32_t>& chunks) {
@@ -1176,13 +1206,21 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             s->n_pieces = (int)(s->h_pieces.size() / 2);
             lrp = s->h_lrp_light.data();
         }
-        build_tile_meta(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg, lrp, g->N, s->h_vmeta);
+        std::vector<int32_t> zero_rp(2 * (size_t)g->N + 1, 0);
+        if (s->p3_bm == ROUND_BM_VAR) {
+            build_tile_meta(g->h_var_seg, g->N, ROUND_BM_VAR, s->h_vtile_seg, s->h_vgseg, lrp, g->N, s->h_vmeta);
+        } else {   // P3 produces on 32-row tiles: the 16-row records only serve P1's fp32 role A as a consumer
+            std::vector<int32_t> none16((size_t)(g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + 1, 0);
+            build_tile_meta(g->h_var_seg, g->N, ROUND_BM_VAR, none16, s->h_vgseg, zero_rp.data(), -1, s->h_vmeta);
+        }
         {   // 64-row records for P1's role B (graphs, first graph's rows / segments; no CSR ranges, no segment base)
-            std::vector<int32_t> none((size_t)(g->N + 63) / 64 + 1, 0), zero_rp(2 * (size_t)g->N + 1, 0);
+            std::vector<int32_t> none((size_t)(g->N + 63) / 64 + 1, 0);
             build_tile_meta(g->h_var_seg, g->N, 64, none, s->h_vgseg, zero_rp.data(), -1, s->h_vmeta4);
-            // ... and 32-row records for role A on 32-row tiles, behind them in the same table
+            // ... and 32-row records behind them in the same table: role A on 32-row tiles (consumer), and P3 on
+            // 32-row tiles (producer: segment base and the CSR ranges of its rows)
             std::vector<int32_t> none2((size_t)(g->N + 31) / 32 + 1, 0), meta2;
-            build_tile_meta(g->h_var_seg, g->N, 32, none2, s->h_vgseg, zero_rp.data(), -1, meta2);
+            if (s->p3_bm == 32) build_tile_meta(g->h_var_seg, g->N, 32, s->h_vtile_seg, s->h_vgseg, lrp, g->N, meta2);
+            else build_tile_meta(g->h_var_seg, g->N, 32, none2, s->h_vgseg, zero_rp.data(), -1, meta2);
             s->vmeta2_at = s->h_vmeta4.size();
             s->h_vmeta4.insert(s->h_vmeta4.end(), meta2.begin(), meta2.end());
         }
@@ -2294,7 +2332,8 @@ extern "C" int dsat_session_set_throughput(dsat_session* s, int32_t enable) {
 
 extern "C" int32_t dsat_session_split_mask(const dsat_session* s) {
     if (s == nullptr || !s->use_fused) return 0;
-    return (s->p2_split ? 1 : 0) | (s->p3_split ? 2 : 0) | (s->p1_a2 ? 4 : 0) | (s->ra1.sp_ws[0] != nullptr && s->pair_blocks ? 8 : 0);
+    return (s->p2_split ? 1 : 0) | (s->p3_split ? 2 : 0) | (s->p1_a2 ? 4 : 0) | (s->ra1.sp_ws[0] != nullptr && s->pair_blocks ? 8 : 0) |
+           (s->p3_split && s->p3_bm == 32 ? 16 : 0);
 }
 
 extern "C" int64_t dsat_session_packed_bytes(const dsat_session* s, int32_t* offsets_out) {

@@ -270,6 +270,8 @@ struct RoundArgs {
     int sp_layers;
     int sp_ks[3], sp_nt[3];
     int s_buf1, s_buf2, s_idx, s_idx_cap, s_mean;   // byte offsets (s_idx_cap: ints)
+    int s_bufB, s_stage;                            // P3: hidden B and the fp32 stage of the column sums (byte offsets)
+    int p3_bm;                                      // P3: rows per tile of the split-product form (16, or 32)
     int s_ld_seg, s_ld_hid;                         // row strides of the plane images, bf16 elements
     // LDS plan (float offsets / row strides), filled by plan_round_lds
     int ld_x, ld_a, ld_b, ld_v, off_x, off_a, off_b, off_vlog, off_mean;   // ld_v: row stride of the pre-mix state tile

@@ -1380,14 +1380,15 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3_kern
 // reuses the input planes.  With 16-row tiles the chain is bound by the weight stream (6 bytes per weight through
 // the CU's 64 B/clk vector-memory path), not by the MFMA pipe.
 #if DSAT_ROUND_NWAVES == 16
+template <int BM>   // 16 rows, or 32 (two row blocks per weight fragment: half the weight stream per row; the
+                    // PairNorm segment tables of the session are then built for 32-row producer tiles)
 __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
-    constexpr int BM = ROUND_BM_VAR;
     constexpr int PASSES = BM / ROUND_NWAVES;   // variables per wave
 #ifndef DSAT_GJ3
 #define DSAT_GJ3 4
 #endif
-    constexpr int GJ = DSAT_GJ3;                // clause rows in flight per literal (x PASSES x 2 arrays)
+    constexpr int GJ = BM > 16 ? (DSAT_GJ3 + 1) / 2 : DSAT_GJ3;   // clause rows in flight per literal (x PASSES x 2 arrays)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.N, NL = a.NL;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -1403,7 +1404,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
     const int ldx = a.s_ld_seg, ldh = a.s_ld_hid;
     const int xpl = BM * ldx;                          // elements per input plane
     unsigned short* hA = reinterpret_cast<unsigned short*>(sbytes + a.s_buf2);
-    unsigned short* hB = hA + 3 * BM * ldh;
+    unsigned short* hB = reinterpret_cast<unsigned short*>(sbytes + a.s_bufB);   // 32 rows: over the input planes
     float* sPart = reinterpret_cast<float*>(sbytes + a.s_mean);
     // unit = [variables_grad | variables | aux | loss_pos | loss_neg]        (query_sat.py:277)
     constexpr int OFF_V = F, OFF_AUX = 2 * F, OFF_POS = 2 * F + AUX_W, OFF_NEG = 3 * F + AUX_W;
@@ -1557,7 +1558,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
         };
         // R12: new_variables = update_gate(unit)
         float* newv = a.newv;
-        float* stage = reinterpret_cast<float*>(xs);   // the input planes are dead once layer 0 has run
+        float* stage = reinterpret_cast<float*>(sbytes + a.s_stage);   // a region that is dead during the last layer
         const int lds = F + 8;
         const int wvu = __builtin_amdgcn_readfirstlane(wave);
         auto final_store = [=](int row, int col, float4 v) {
@@ -1573,7 +1574,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
             sc.nlayers = a.sp_layers;
 #pragma unroll
             for (int l = 0; l < 3; ++l) sc.L[l] = SplitLayer{a.sp_ws[l], a.mupd.L[l].bias, a.sp_ks[l], a.sp_nt[l]};
-            split_chain<1, NT, DSAT_SPLIT_PD1>(sc, xs, ldx, hA, hB, ldh, wvu, lane, tid, final_store, finish);
+            split_chain<BM / 16, NT, (BM > 16 ? DSAT_SPLIT_PD4 : DSAT_SPLIT_PD1)>(sc, xs, ldx, hA, hB, ldh, wvu, lane, tid, final_store, finish);
         }
         DSAT_STAMP(a, 2);
         tile_colsums<BM>(tile_lo, N, tm, a.var_seg, a.psum_v, stage, lds, sPart, tid);
@@ -1832,7 +1833,8 @@ hipError_t launch_round_p3(const RoundArgs& a, hipStream_t st) {
     const int tiles = (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
 #if DSAT_ROUND_NWAVES == 16
     if (a.sp_ws[0] != nullptr) {
-        hipLaunchKernelGGL(round_p3s_kernel, dim3(tiles), dim3(NT), 0, st, a);
+        if (a.p3_bm == 32) hipLaunchKernelGGL(round_p3s_kernel<32>, dim3((a.N + 31) / 32), dim3(NT), 0, st, a);
+        else hipLaunchKernelGGL(round_p3s_kernel<16>, dim3(tiles), dim3(NT), 0, st, a);
         return hipGetLastError();
     }
 #endif

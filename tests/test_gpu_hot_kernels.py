@@ -59,13 +59,13 @@ def _instances(kind):
 
 # the three forms the round runs in: fused tiles with the clause / update MLPs on the bf16 pipe (fp32 products from
 # bf16 slices, the default), fused tiles on v_mfma_f32_16x16x4_f32 only, and the per-layer kernels
-# ... and "fused_a2": as "fused", with P1's lit_mlp on 32-row split-product tiles (what batches of more than one wave
-# of workgroups, and sessions told to prefer throughput, run)
+# ... and "fused_a2": as "fused", with P1's lit_mlp and P3 on 32-row split-product tiles (what batches of more than one
+# wave of workgroups run; sessions told to prefer throughput get the first)
 VARIANTS = ["fused", "fused_a2", "fused_f32mfma", "per_layer"]
 
 
 def _session(rt, batch, ws, max_rounds, fused):
-    env = {"per_layer": {"DSAT_FUSED": "0"}, "fused_a2": {"DSAT_P1_A2": "1"},
+    env = {"per_layer": {"DSAT_FUSED": "0"}, "fused_a2": {"DSAT_P1_A2": "1", "DSAT_P3_BM": "32"},
            "fused_f32mfma": {"DSAT_P2_SPLIT": "0", "DSAT_P3_SPLIT": "0", "DSAT_P1_A2": "0", "DSAT_P1_BSPLIT": "0"}}.get(fused, {})
     if fused is False:
         env = {"DSAT_FUSED": "0"}
@@ -80,7 +80,7 @@ def _session(rt, batch, ws, max_rounds, fused):
     if fused == "fused":
         assert s.split_mask() & 3 == 3    # the released layout runs both split-product tiles
     if fused == "fused_a2":
-        assert s.split_mask() & 7 == 7
+        assert s.split_mask() & 23 == 23      # ... and P3 on 32-row tiles
     return s
 
 
