@@ -680,6 +680,8 @@ struct dsat_session {
     std::vector<int32_t> h_vmeta4;
     int32_t* vmeta4 = nullptr;
     size_t vmeta2_at = 0;   // offset (int32) of the 32-row records inside vmeta4
+    size_t vlist_at = 0, clist_at = 0;   // ... and of the per-tile list blocks (build_list_blocks)
+    int vlist_stride = 0, vlist_max = 0, clist_stride = 0, clist_max = 0;
     int p1_a2 = 0;          // P1 role A runs on 32-row tiles with split products (role_a2)
     int p1_a2_ok = 0;       // ... is possible for this session (shapes, LDS, role B present)
     int p1_a2_env = -1;     // DSAT_P1_A2: 0 never, 1 always, -1 (unset) by batch size / dsat_session_set_throughput
@@ -821,6 +823,41 @@ static void build_tile_meta(const std::vector<int32_t>& seg, int rows, int bm, c
     }
 }
 
+// Per-tile list blocks: the CSR lists of a tile's rows copied out at a FIXED stride, so that a tile's workgroup knows
+// the address from its index alone and fetches the lists in the same memory round trip as its tile record (whose
+// e_base / e_end it would otherwise have to wait for first).  Block = [ptr0 (bm+1, relative) | ptr1 (bm+1, offset by
+// the length of list 0; only with neg_off >= 0) | entries of list 0 | entries of list 1].  Tiles whose lists exceed
+// `cap` entries keep an empty block (the kernels then read the global CSR; `*max_n` tells them which).
+static int build_list_blocks(const int32_t* rowptr, const int32_t* idx, int rows, int bm, int neg_off, int cap,
+                             std::vector<int32_t>& out, size_t* at, int* max_n) {
+    const int ntiles = (rows + bm - 1) / bm, nl = neg_off >= 0 ? 2 : 1, hdr = nl * (bm + 1);
+    int mx = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int lo = t * bm, hi = std::min(rows, lo + bm);
+        int n = rowptr[hi] - rowptr[lo];
+        if (nl == 2) n += rowptr[neg_off + hi] - rowptr[neg_off + lo];
+        if (n <= cap) mx = std::max(mx, n);
+    }
+    const int stride = round_up(hdr + mx, 4);
+    *at = out.size();
+    *max_n = mx;
+    out.resize(*at + (size_t)std::max(ntiles, 1) * stride, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int lo = t * bm, hi = std::min(rows, lo + bm);
+        const int n0 = rowptr[hi] - rowptr[lo];
+        const int n1 = nl == 2 ? rowptr[neg_off + hi] - rowptr[neg_off + lo] : 0;
+        if (n0 + n1 > mx) continue;
+        int32_t* b = &out[*at + (size_t)t * stride];
+        for (int i = 0; i <= bm; ++i) {
+            b[i] = rowptr[std::min(lo + i, hi)] - rowptr[lo];
+            if (nl == 2) b[bm + 1 + i] = n0 + rowptr[neg_off + std::min(lo + i, hi)] - rowptr[neg_off + lo];
+        }
+        std::copy(idx + rowptr[lo], idx + rowptr[hi], b + hdr);
+        if (nl == 2) std::copy(idx + rowptr[neg_off + lo], idx + rowptr[neg_off + hi], b + hdr + n0);
+    }
+    return stride;
+}
+
 static ChainSpec make_chain(const std::vector<PackedLayer>& layers, int rb) {
     ChainSpec c;
     memset(&c, 0, sizeof(c));
@@ -898,6 +935,8 @@ static bool plan_round(dsat_session* s) {
     a.vgseg2 = s->n_vchunks > 0 ? s->vgseg2 : nullptr; a.psum2_v = s->psum2_v;
     a.cgseg2 = s->n_cchunks > 0 ? s->cgseg2 : nullptr; a.psum2_c = s->psum2_c;
     a.sel_tab = s->sel_tab; a.n_sel = s->n_sel; a.sel_zero = s->sel_zero;
+    a.vlist = s->vlist_stride > 0 ? s->vmeta4 + s->vlist_at : nullptr; a.vlist_stride = s->vlist_stride; a.vlist_max = s->vlist_max;
+    a.clist = s->clist_stride > 0 ? s->vmeta4 + s->clist_at : nullptr; a.clist_stride = s->clist_stride; a.clist_max = s->clist_max;
     a.sel_lead = s->sel_zero ? round_up(s->n_sel, 8) : 0;   // long select parts (a large graph) go first
     a.V = s->V; a.Cs = s->Cs; a.q = s->q; a.sp = s->sp; a.lits = s->lits; a.closs4 = s->closs4;
     a.vla = s->vla; a.ncv = s->ncv; a.newv = s->newv; a.logits = s->logits;
@@ -1032,6 +1071,9 @@ static bool plan_round(dsat_session* s) {
                 s->p2_split = 1;
             }
         }
+        // the tile's list block must fit where the kernel stages it (and P2's tile size must be the blocks')
+        if (r.clist != nullptr && (rb != s->p2_rb || r.clist_stride > (s->p2_split ? r.s_idx_cap + bm + 8 : bm * r.ld_a)))
+            r.clist = nullptr;
         if (getenv("DSAT_DEBUG_PLAN") != nullptr)
             fprintf(stderr, "[dsat] P2 rb=%d split=%d (buf2 at %d, lists at %d cap %d, sums at %d of %d bytes)\n", rb,
                     s->p2_split, r.s_buf2, r.s_idx, r.s_idx_cap, r.s_mean, LDS * 4);
@@ -1093,6 +1135,8 @@ static bool plan_round(dsat_session* s) {
             }
         }
         if (s->p3_bm == 32 && !s->p3_split) ok = false;   // the tables were built for 32-row producer tiles
+        if (r.vlist != nullptr && r.vlist_stride > (s->p3_split ? 2 * r.s_idx_cap + 2 * (s->p3_bm + 8) : ROUND_BM_VAR * r.ld_a))
+            r.vlist = nullptr;
         if (getenv("DSAT_DEBUG_PLAN") != nullptr)
             fprintf(stderr, "[dsat] P3 split=%d rows %d (ldx %d ldh %d, hidden at %d, lists cap %d, sums at %d of %d bytes)\n",
                     s->p3_split, s->p3_bm, r.s_ld_seg, r.s_ld_hid, r.s_buf2, r.s_idx_cap, r.s_mean, LDS * 4);
@@ -1224,6 +1268,9 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             s->vmeta2_at = s->h_vmeta4.size();
             s->h_vmeta4.insert(s->h_vmeta4.end(), meta2.begin(), meta2.end());
         }
+        if (getenv("DSAT_NO_LISTBLOCKS") == nullptr)   // the literal -> clause lists of P3's tiles at a fixed stride
+            s->vlist_stride = build_list_blocks(lrp, s->n_pieces > 0 ? s->h_lcl_light.data() : g->h_l_clause.data(), g->N,
+                                                s->p3_bm, g->N, LIST_BLOCK_CAP, s->h_vmeta4, &s->vlist_at, &s->vlist_max);
         const int32_t* crp = g->h_c_rowptr.data();
         if (g->max_clause_len > s->heavy_t) {   // heavy clauses: the mirror image of the heavy literal rows
             s->h_crp_light.assign((size_t)g->C + 1, 0);
@@ -1250,6 +1297,9 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             crp = s->h_crp_light.data();
         }
         build_tile_meta(g->h_cl_seg, g->C, 16 * rb, s->h_ctile_seg, s->h_cgseg, crp, -1, s->h_cmeta);
+        if (getenv("DSAT_NO_LISTBLOCKS") == nullptr)   // the clause -> literal lists of P2's tiles likewise
+            s->clist_stride = build_list_blocks(crp, s->n_cpieces > 0 ? s->h_ccl_light.data() : g->h_c_lit.data(), g->C,
+                                                16 * rb, -1, LIST_BLOCK_CAP, s->h_vmeta4, &s->clist_at, &s->clist_max);
     }
     Slab dry;
     carve(s.get(), dry);

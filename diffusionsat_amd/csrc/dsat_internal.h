@@ -261,6 +261,10 @@ struct RoundArgs {
     // P1 role A on 32-row tiles with lit_mlp's products formed from bf16 slices (kernels_round.hip, role_a2):
     // a2_tiles > 0 replaces the 16-row A tiles; role B then covers every 64-row group
     const int32_t* vmeta2;  // 32-row records (as vmeta4)
+    // per-tile list blocks at a fixed stride (dsat_api.hip, build_list_blocks): P3's tiles (two lists), P2's (one);
+    // nullptr = none, *_max = the longest block that was copied (longer tiles read the global CSR)
+    const int32_t *vlist, *clist;
+    int vlist_stride, vlist_max, clist_stride, clist_max;
     int a2_tiles;
     const uint4* a2_ws[3];  // lit_mlp's three layers as bf16 slices
     // P2 / P3 with fp32 products formed from bf16 slices (round_p2s_kernel, round_p3s_kernel, split_bf16.h): per
@@ -277,6 +281,7 @@ struct RoundArgs {
     int ld_x, ld_a, ld_b, ld_v, off_x, off_a, off_b, off_vlog, off_mean;   // ld_v: row stride of the pre-mix state tile
 };
 constexpr int TILE_META_INTS = 16;
+constexpr int LIST_BLOCK_LOADS = 4;    // ints per thread with which a workgroup fetches a tile's list block
 constexpr int ROUND_BM_VAR = 16;    // rows per variable-side tile
 // Waves per workgroup of the round kernels (8 or 16; one workgroup per CU either way).  16 = four
 // waves per SIMD at <= 128 VGPRs each: with the shallow weight ring that fits, and the tile
@@ -288,6 +293,7 @@ constexpr int ROUND_BM_VAR = 16;    // rows per variable-side tile
 #endif
 constexpr int ROUND_NWAVES = DSAT_ROUND_NWAVES;
 static_assert(ROUND_NWAVES == 8 || ROUND_NWAVES == 16, "round kernels are written for 8 or 16 waves");
+constexpr int LIST_BLOCK_CAP = (LIST_BLOCK_LOADS * ROUND_NWAVES * 64 - 136 < 3840) ? LIST_BLOCK_LOADS * ROUND_NWAVES * 64 - 136 : 3840;   // entries of a tile's list block
 // LDS of one round-kernel workgroup, in floats: all 160 KiB of the CU (one workgroup per CU), or, for the
 // two-workgroups-per-CU experiment (-DDSAT_ROUND_NWAVES=8 -DDSAT_ROUND_LDS_FLOATS=20480), half of it
 #ifndef DSAT_ROUND_LDS_FLOATS

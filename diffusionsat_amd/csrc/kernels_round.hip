@@ -400,6 +400,25 @@ __device__ __forceinline__ bool stage_csr(const int32_t* __restrict__ rowptr, co
     return true;
 }
 
+// A tile's list block (dsat_api.hip, build_list_blocks): fetched by the whole workgroup at an address that only
+// depends on the tile index -- in the same memory round trip as the tile record -- and written to LDS once the
+// workgroup knows it has work to do.
+struct ListBlock { int r[LIST_BLOCK_LOADS]; };
+__device__ __forceinline__ void list_block_fetch(ListBlock& lb, const int32_t* __restrict__ table, int stride, int tile, int tid) {
+#pragma unroll
+    for (int i = 0; i < LIST_BLOCK_LOADS; ++i) {
+        const int k = tid + i * NT;
+        lb.r[i] = (table != nullptr && k < stride) ? table[(size_t)tile * stride + k] : 0;
+    }
+}
+__device__ __forceinline__ void list_block_store(const ListBlock& lb, int* dst, int stride, int tid) {
+#pragma unroll
+    for (int i = 0; i < LIST_BLOCK_LOADS; ++i) {
+        const int k = tid + i * NT;
+        if (k < stride) dst[k] = lb.r[i];
+    }
+}
+
 // R15-R17 for one graph (forward declaration; defined with the stand-alone kernel below)
 template <int NTH>
 __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int32_t* __restrict__ sel_tab,
@@ -779,6 +798,8 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
     const int tile = extra ? 0 : xcd_tile(tb, tiles);
     const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
     const TileMetaDev tm = load_meta(a.cmeta, tile);
+    ListBlock lb;                                       // ... and with the tile's clause -> literal lists
+    list_block_fetch(lb, extra ? nullptr : a.clist, a.clist_stride, tile, tid);
     if (both_arrived(done, tm) != 0) return;
     if (extra) {
         DSAT_STAMP_RT_BEGIN(a);
@@ -803,8 +824,15 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
     // the clause rows' literal lists -> LDS (sA is free until the first layer writes it)
     int* sPtr = reinterpret_cast<int*>(sA);
     int* sIdx = sPtr + BM + 8;
-    const bool staged = stage_csr(a.cg_rowptr, a.cg_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr,
-                                  sIdx, BM * a.ld_a - (BM + 8), tid);
+    bool staged;
+    if (a.clist != nullptr) {   // the block is [ptr | list]
+        list_block_store(lb, sPtr, a.clist_stride, tid);
+        sIdx = sPtr + BM + 1;
+        staged = tm.e_end0 - tm.e_base0 <= a.clist_max;
+    } else {
+        staged = stage_csr(a.cg_rowptr, a.cg_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr, sIdx,
+                           BM * a.ld_a - (BM + 8), tid);
+    }
     if (a.cs_ready && a.round > 0) {   // R10 was finished by P1's extra blocks: just load the rows
         const int sub = tid & 31, hw = tid >> 5;
 #pragma unroll
@@ -962,6 +990,8 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
     const int tile = extra ? 0 : xcd_tile(tb, tiles);
     const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
     const TileMetaDev tm = load_meta(a.cmeta, tile);
+    ListBlock lb;                                       // ... and with the tile's clause -> literal lists
+    list_block_fetch(lb, extra ? nullptr : a.clist, a.clist_stride, tile, tid);
     if (both_arrived(done, tm) != 0) return;
     if (extra) {
         DSAT_STAMP_RT_BEGIN(a);
@@ -980,6 +1010,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
     unsigned short* buf2 = reinterpret_cast<unsigned short*>(sbytes + a.s_buf2);
     int* sPtr = reinterpret_cast<int*>(sbytes + a.s_idx);
     int* sIdx = sPtr + BM + 8;
+    bool staged;
     float* sMean = reinterpret_cast<float*>(sbytes + a.s_mean);
     const int ldg = a.s_ld_seg, ldh = a.s_ld_hid;
     const int pl_seg = BM * ldg, pl_hid = BM * ldh;   // elements per plane
@@ -987,8 +1018,14 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
 
     DSAT_STAMP_RT_BEGIN(a);
     DSAT_STAMP(a, 0);
-    const bool staged = stage_csr(a.cg_rowptr, a.cg_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr,
-                                  sIdx, a.s_idx_cap, tid);
+    if (a.clist != nullptr) {   // the block is [ptr | list]
+        list_block_store(lb, sPtr, a.clist_stride, tid);
+        sIdx = sPtr + BM + 1;
+        staged = tm.e_end0 - tm.e_base0 <= a.clist_max;
+    } else {
+        staged = stage_csr(a.cg_rowptr, a.cg_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr, sIdx,
+                           a.s_idx_cap, tid);
+    }
     if (a.cs_ready && a.round > 0) {   // R10 was finished by P1's extra blocks: load the rows, slice them
 #pragma unroll
         for (int kq = 0; kq < ROWS; ++kq) {
@@ -1199,6 +1236,8 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3_kern
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
     const TileMetaDev tm = load_meta(a.vmeta, tile);
+    ListBlock lb;                                       // ... and with the tile's literal -> clause lists
+    list_block_fetch(lb, a.vlist, a.vlist_stride, tile, tid);
     if (both_arrived(done, tm) != 0) return;
     if (a.sel_zero && blockIdx.x == 0)   // multi-part select adds its counts up: start the next one from zero
         for (int g = tid; g < a.G; g += NT) a.graph_unsat[g] = 0;
@@ -1223,9 +1262,18 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3_kern
         const int cap = (BM * a.ld_a - 2 * (BM + 8)) / 2;
         int* sIdx1 = sIdx0 + cap;
         const int nrows = tile_hi - tile_lo;
-        const bool st0 = stage_csr(a.l_rowptr, a.l_clause, tile_lo, nrows, tm.e_base0, tm.e_end0, sPtr0, sIdx0, cap, tid);
-        const bool st1 = stage_csr(a.l_rowptr, a.l_clause, NL + tile_lo, nrows, tm.e_base1, tm.e_end1, sPtr1, sIdx1, cap, tid);
-        const bool staged = st0 && st1;
+        bool staged;
+        if (a.vlist != nullptr) {   // the block is [ptr0 | ptr1 (offset by list 0's length) | list 0 | list 1]
+            list_block_store(lb, sPtr0, a.vlist_stride, tid);
+            sPtr1 = sPtr0 + BM + 1;
+            sIdx0 = sPtr1 + BM + 1;
+            sIdx1 = sIdx0;
+            staged = (tm.e_end0 - tm.e_base0) + (tm.e_end1 - tm.e_base1) <= a.vlist_max;
+        } else {
+            const bool st0 = stage_csr(a.l_rowptr, a.l_clause, tile_lo, nrows, tm.e_base0, tm.e_end0, sPtr0, sIdx0, cap, tid);
+            const bool st1 = stage_csr(a.l_rowptr, a.l_clause, NL + tile_lo, nrows, tm.e_base1, tm.e_end1, sPtr1, sIdx1, cap, tid);
+            staged = st0 && st1;
+        }
         // rows that do not depend on the lists: q (half 0) and the carried state (half 1)
         float4 rowv[PASSES], qrow[PASSES];
         float wdeg[PASSES], wv[PASSES];
@@ -1394,6 +1442,8 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
     const TileMetaDev tm = load_meta(a.vmeta, tile);
+    ListBlock lb;                                       // ... and with the tile's literal -> clause lists
+    list_block_fetch(lb, a.vlist, a.vlist_stride, tile, tid);
     if (both_arrived(done, tm) != 0) return;
     if (a.sel_zero && blockIdx.x == 0)   // multi-part select adds its counts up: start the next one from zero
         for (int g = tid; g < a.G; g += NT) a.graph_unsat[g] = 0;
@@ -1420,9 +1470,18 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
         const int cap = a.s_idx_cap;
         int* sIdx1 = sIdx0 + cap;
         const int nrows = tile_hi - tile_lo;
-        const bool st0 = stage_csr(a.l_rowptr, a.l_clause, tile_lo, nrows, tm.e_base0, tm.e_end0, sPtr0, sIdx0, cap, tid);
-        const bool st1 = stage_csr(a.l_rowptr, a.l_clause, NL + tile_lo, nrows, tm.e_base1, tm.e_end1, sPtr1, sIdx1, cap, tid);
-        const bool staged = st0 && st1;
+        bool staged;
+        if (a.vlist != nullptr) {   // the block is [ptr0 | ptr1 (offset by list 0's length) | list 0 | list 1]
+            list_block_store(lb, sPtr0, a.vlist_stride, tid);
+            sPtr1 = sPtr0 + BM + 1;
+            sIdx0 = sPtr1 + BM + 1;
+            sIdx1 = sIdx0;
+            staged = (tm.e_end0 - tm.e_base0) + (tm.e_end1 - tm.e_base1) <= a.vlist_max;
+        } else {
+            const bool st0 = stage_csr(a.l_rowptr, a.l_clause, tile_lo, nrows, tm.e_base0, tm.e_end0, sPtr0, sIdx0, cap, tid);
+            const bool st1 = stage_csr(a.l_rowptr, a.l_clause, NL + tile_lo, nrows, tm.e_base1, tm.e_end1, sPtr1, sIdx1, cap, tid);
+            staged = st0 && st1;
+        }
         // rows that do not depend on the lists: q (half 0) and the carried state (half 1)
         float4 rowv[PASSES], qrow[PASSES];
         float wdeg[PASSES], wv[PASSES];
