@@ -992,6 +992,17 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
     const TileMetaDev tm = load_meta(a.cmeta, tile);
     ListBlock lb;                                       // ... and with the tile's clause -> literal lists
     list_block_fetch(lb, extra ? nullptr : a.clist, a.clist_stride, tile, tid);
+    const int tile_lo = tile * BM;
+    const int tile_hi = min(tile_lo + BM, C);
+    // ... and with the carried clause state of the tile's rows (finished by P1's extra blocks)
+    const bool rows_ready = !extra && a.cs_ready && a.round > 0;
+    float4 srow[ROWS];
+#pragma unroll
+    for (int kq = 0; kq < ROWS; ++kq) {
+        const int r = (tid >> 5) + kq * (NT / 32);
+        srow[kq] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rows_ready && tile_lo + r < tile_hi) srow[kq] = ld4(a.Cs + (size_t)(tile_lo + r) * F + (tid & 31) * 4);
+    }
     if (both_arrived(done, tm) != 0) return;
     if (extra) {
         DSAT_STAMP_RT_BEGIN(a);
@@ -1003,8 +1014,6 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
         DSAT_STAMP_RT_END(a);
         return;
     }
-    const int tile_lo = tile * BM;
-    const int tile_hi = min(tile_lo + BM, C);
     unsigned char* sbytes = reinterpret_cast<unsigned char*>(smem);
     unsigned short* buf1 = reinterpret_cast<unsigned short*>(sbytes + a.s_buf1);
     unsigned short* buf2 = reinterpret_cast<unsigned short*>(sbytes + a.s_buf2);
@@ -1026,14 +1035,9 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
         staged = stage_csr(a.cg_rowptr, a.cg_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr, sIdx,
                            a.s_idx_cap, tid);
     }
-    if (a.cs_ready && a.round > 0) {   // R10 was finished by P1's extra blocks: load the rows, slice them
+    if (rows_ready) {   // R10 was finished by P1's extra blocks: slice the rows loaded above
 #pragma unroll
-        for (int kq = 0; kq < ROWS; ++kq) {
-            const int r = hw + kq * (NT / 32);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tile_lo + r < tile_hi) v = ld4(a.Cs + (size_t)(tile_lo + r) * F + sub * 4);
-            split_st4(buf1, pl_seg, r * ldg + sub * 4, v);
-        }
+        for (int kq = 0; kq < ROWS; ++kq) split_st4(buf1, pl_seg, (hw + kq * (NT / 32)) * ldg + sub * 4, srow[kq]);
         __syncthreads();
     } else {   // PairNorm here, in fp32 (buf2 is free: rows, then the thread groups' partial sums), then the slices
         float* scratch = reinterpret_cast<float*>(buf2);
@@ -1444,11 +1448,30 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
     const TileMetaDev tm = load_meta(a.vmeta, tile);
     ListBlock lb;                                       // ... and with the tile's literal -> clause lists
     list_block_fetch(lb, a.vlist, a.vlist_stride, tile, tid);
+    const int tile_lo = tile * BM;
+    const int tile_hi = min(tile_lo + BM, N);
+    // ... and with the rows that do not depend on the lists: q (half 0) and the carried state (half 1)
+    float4 rowv[PASSES], qrow[PASSES];
+    float wdeg[PASSES], wv[PASSES];
+    int2 hv[PASSES];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+        const int v = tile_lo + wave + u * ROUND_NWAVES, half_ = lane >> 5, sub_ = lane & 31;
+        rowv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        qrow[u] = rowv[u];
+        wdeg[u] = 0.f; wv[u] = 0.f;
+        hv[u] = make_int2(-1, 0);
+        if (v < N) {
+            if (a.l_hv != nullptr) hv[u] = a.l_hv[v + half_ * NL];
+            qrow[u] = ld4(a.q + (size_t)v * F + sub_ * 4);
+            if (half_ == 1) rowv[u] = ld4(a.V + (size_t)v * F + sub_ * 4);
+            wdeg[u] = a.deg_w[v + half_ * NL];
+            wv[u] = a.vdeg_w[v];
+        }
+    }
     if (both_arrived(done, tm) != 0) return;
     if (a.sel_zero && blockIdx.x == 0)   // multi-part select adds its counts up: start the next one from zero
         for (int g = tid; g < a.G; g += NT) a.graph_unsat[g] = 0;
-    const int tile_lo = tile * BM;
-    const int tile_hi = min(tile_lo + BM, N);
     unsigned char* sbytes = reinterpret_cast<unsigned char*>(smem);
     unsigned short* xs = reinterpret_cast<unsigned short*>(sbytes + a.s_buf1);
     const int ldx = a.s_ld_seg, ldh = a.s_ld_hid;
@@ -1481,25 +1504,6 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
             const bool st0 = stage_csr(a.l_rowptr, a.l_clause, tile_lo, nrows, tm.e_base0, tm.e_end0, sPtr0, sIdx0, cap, tid);
             const bool st1 = stage_csr(a.l_rowptr, a.l_clause, NL + tile_lo, nrows, tm.e_base1, tm.e_end1, sPtr1, sIdx1, cap, tid);
             staged = st0 && st1;
-        }
-        // rows that do not depend on the lists: q (half 0) and the carried state (half 1)
-        float4 rowv[PASSES], qrow[PASSES];
-        float wdeg[PASSES], wv[PASSES];
-        int2 hv[PASSES];
-#pragma unroll
-        for (int u = 0; u < PASSES; ++u) {
-            const int v = tile_lo + wave + u * ROUND_NWAVES;
-            rowv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            qrow[u] = rowv[u];
-            wdeg[u] = 0.f; wv[u] = 0.f;
-            hv[u] = make_int2(-1, 0);
-            if (v < N) {
-                if (a.l_hv != nullptr) hv[u] = a.l_hv[v + half * NL];
-                qrow[u] = ld4(a.q + (size_t)v * F + sub * 4);
-                if (half == 1) rowv[u] = ld4(a.V + (size_t)v * F + sub * 4);
-                wdeg[u] = a.deg_w[v + half * NL];
-                wv[u] = a.vdeg_w[v];
-            }
         }
         if (tid < 4 * BM) {   // aux columns of the rows (one float4 per thread), and the zero columns up to the end of
             const int r = tid >> 2, q4 = tid & 3;   // the last k-step
