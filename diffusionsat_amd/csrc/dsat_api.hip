@@ -935,6 +935,7 @@ static bool plan_round(dsat_session* s) {
     a.vgseg2 = s->n_vchunks > 0 ? s->vgseg2 : nullptr; a.psum2_v = s->psum2_v;
     a.cgseg2 = s->n_cchunks > 0 ? s->cgseg2 : nullptr; a.psum2_c = s->psum2_c;
     a.sel_tab = s->sel_tab; a.n_sel = s->n_sel; a.sel_zero = s->sel_zero;
+    a.gj2_three = g->max_clause_len <= 3 && getenv("DSAT_GJ2_FOUR") == nullptr;
     a.vlist = s->vlist_stride > 0 ? s->vmeta4 + s->vlist_at : nullptr; a.vlist_stride = s->vlist_stride; a.vlist_max = s->vlist_max;
     a.clist = s->clist_stride > 0 ? s->vmeta4 + s->clist_at : nullptr; a.clist_stride = s->clist_stride; a.clist_max = s->clist_max;
     a.sel_lead = s->sel_zero ? round_up(s->n_sel, 8) : 0;   // long select parts (a large graph) go first

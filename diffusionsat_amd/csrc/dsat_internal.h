@@ -265,6 +265,7 @@ struct RoundArgs {
     // nullptr = none, *_max = the longest block that was copied (longer tiles read the global CSR)
     const int32_t *vlist, *clist;
     int vlist_stride, vlist_max, clist_stride, clist_max;
+    int gj2_three;          // P2: no clause of the batch has more than three literals
     int a2_tiles;
     const uint4* a2_ws[3];  // lit_mlp's three layers as bf16 slices
     // P2 / P3 with fp32 products formed from bf16 slices (round_p2s_kernel, round_p3s_kernel, split_bf16.h): per
