@@ -33,19 +33,26 @@ namespace {
 constexpr int NT = ROUND_NWAVES * 64;
 
 // Phase stamps for the diagnostic build of a session (never read by any kernel).
+// -DDSAT_STAMP_ROTATE (diagnostic builds): workgroup b's stamps are taken by wave b mod 16 instead of wave 0, so a
+// launch shows how the waves of a workgroup differ (tools/stamps_waves.py)
+#ifdef DSAT_STAMP_ROTATE
+#define DSAT_STAMP_THREAD ((blockIdx.x & 15u) * 64u)
+#else
+#define DSAT_STAMP_THREAD 0u
+#endif
 #define DSAT_STAMP(a, k)                                                                  \
     do {                                                                                  \
-        if ((a).stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096)                 \
+        if ((a).stamps != nullptr && threadIdx.x == DSAT_STAMP_THREAD && blockIdx.x < 4096) \
             (a).stamps[blockIdx.x * 8 + (k)] = clock64();                                   \
     } while (0)
 // Slot 7 of a tile's stamps: the 100 MHz real-time counter's ticks between the tile's first and last
 // stamp, so that tools/stamps.py can turn shader-clock cycles into time and report the clock the
 // kernel actually ran at (MI355X_MICROARCH.md, DVFS give-back item 6).
 #define DSAT_STAMP_RT_BEGIN(a) \
-    const unsigned long long _rt0 = ((a).stamps != nullptr && threadIdx.x == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull
+    const unsigned long long _rt0 = ((a).stamps != nullptr && threadIdx.x == DSAT_STAMP_THREAD) ? __builtin_amdgcn_s_memrealtime() : 0ull
 #define DSAT_STAMP_RT_END(a)                                                              \
     do {                                                                                  \
-        if ((a).stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096)                 \
+        if ((a).stamps != nullptr && threadIdx.x == DSAT_STAMP_THREAD && blockIdx.x < 4096) \
             (a).stamps[blockIdx.x * 8 + 7] = (long long)(__builtin_amdgcn_s_memrealtime() - _rt0); \
     } while (0)
 // Epilogue addresses are per-lane 64-bit values; computed from loop-invariant inputs, the compiler
