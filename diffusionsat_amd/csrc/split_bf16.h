@@ -105,6 +105,23 @@ __device__ __forceinline__ void split_step(const SplitSlot& w, bf16x8 xh, bf16x8
     }
 }
 
+// The matrix pipe serves the oldest of a SIMD's waves first, so four waves with the same work finish a k-loop up to
+// 9 k cycles apart and the last one runs its tail alone, latencies exposed.  Rotating the issue priority among the
+// SIMD's four waves from k-step to k-step keeps them together: 359.7 -> 363.8 steps/s at config 2 (P3 22.2 -> 21.8
+// us; the same rotation in the fp32 chains of fused_common.h cost P1 4 us and is not used there).
+// -DDSAT_SPLIT_NO_ROTPRIO turns it off.
+__device__ __forceinline__ void split_rotate_prio(int step) {
+#ifndef DSAT_SPLIT_NO_ROTPRIO
+    const int x = (step + (int)(threadIdx.x >> 8)) & 3;
+    if (x == 0) __builtin_amdgcn_s_setprio(0);
+    else if (x == 1) __builtin_amdgcn_s_setprio(1);
+    else if (x == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+#else
+    (void)step;
+#endif
+}
+
 // k-steps [s0, s1) of a primed ring (s0 and s1 - s0 multiples of PD; slot p holds step s0 + p on entry and
 // min(s1 + p, stot - 1) on return).  `px`: the lane's element of plane 0 in a buffer whose column 0 is step sbuf0.
 template <int NRB, int PD>
@@ -116,6 +133,7 @@ __device__ __forceinline__ void split_ring_steps(SplitSlot (&ring)[PD], unsigned
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
             const unsigned short* q = px + (s + p - sbuf0) * 32;
+            split_rotate_prio(s + p);
             const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q), xm = *reinterpret_cast<const bf16x8*>(q + plane),
                          xl = *reinterpret_cast<const bf16x8*>(q + 2 * plane);
             // slot p was requested PD steps ago; 3 * (PD - 1) younger loads may stay in flight
@@ -136,6 +154,9 @@ template <int NRB, int PD>
 __device__ __forceinline__ void split_ring_tail(SplitSlot (&ring)[PD], int s1, int stot, const unsigned short* px,
                                                 int plane, int ld, int sbuf0, sf32x4 (&acc)[NRB]) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0].h), "+v"(ring[0].m), "+v"(ring[0].l) :: "memory");
+#ifndef DSAT_SPLIT_NO_ROTPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
     for (int p = 1; p < PD; ++p) asm volatile("" : "+v"(ring[p].h), "+v"(ring[p].m), "+v"(ring[p].l));
 #pragma unroll
@@ -178,6 +199,7 @@ __device__ __forceinline__ void split_layer_segments(unsigned voff, const float4
 #pragma unroll
             for (int p = 0; p < PD; ++p) {
                 const unsigned short* q = px + p * 32;
+                split_rotate_prio(s + p);
                 const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q), xm = *reinterpret_cast<const bf16x8*>(q + plane),
                              xl = *reinterpret_cast<const bf16x8*>(q + 2 * plane);
                 asm volatile("s_waitcnt vmcnt(%3)" : "+v"(ring[p].h), "+v"(ring[p].m), "+v"(ring[p].l) : "n"(3 * (PD - 1)) : "memory");
@@ -192,6 +214,9 @@ __device__ __forceinline__ void split_layer_segments(unsigned voff, const float4
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0].h), "+v"(ring[0].m), "+v"(ring[0].l) :: "memory");
+#ifndef DSAT_SPLIT_NO_ROTPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
         for (int p = 1; p < PD; ++p) asm volatile("" : "+v"(ring[p].h), "+v"(ring[p].m), "+v"(ring[p].l));
     }
