@@ -112,7 +112,10 @@ __device__ __forceinline__ void split_step(const SplitSlot& w, bf16x8 xh, bf16x8
 // -DDSAT_SPLIT_NO_ROTPRIO turns it off.
 __device__ __forceinline__ void split_rotate_prio(int step) {
 #ifndef DSAT_SPLIT_NO_ROTPRIO
-    const int x = (step + (int)(threadIdx.x >> 8)) & 3;
+#ifndef DSAT_ROT_SHIFT
+#define DSAT_ROT_SHIFT 1   // a turn lasts two k-steps (0: 359.0, 1: 360.9, 2: 358.2 steps/s on one box)
+#endif
+    const int x = ((step >> DSAT_ROT_SHIFT) + (int)(threadIdx.x >> 8)) & 3;
     if (x == 0) __builtin_amdgcn_s_setprio(0);
     else if (x == 1) __builtin_amdgcn_s_setprio(1);
     else if (x == 2) __builtin_amdgcn_s_setprio(2);
