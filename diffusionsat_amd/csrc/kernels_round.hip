@@ -1159,11 +1159,9 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
             const int r = hw + u * (NT / 32);
             const int c = tile_lo + r;
             float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < C) {
-                cl = make_float4(4.f * expf(-S[u].x), 4.f * expf(-S[u].y), 4.f * expf(-S[u].z), 4.f * expf(-S[u].w));
-                stg4(a.closs4 + (size_t)c * F + sub * 4, cl);
-            }
-            clv[u] = cl;
+            if (c < C) cl = make_float4(4.f * expf(-S[u].x), 4.f * expf(-S[u].y), 4.f * expf(-S[u].z), 4.f * expf(-S[u].w));
+            clv[u] = cl;   // (stored to closs4 at the end of the tile: a write-through store here would sit in front of
+                           // the weight ring's counted waits until it is acknowledged)
             const float rw = rwv[u];
             const float4 cm = make_float4(M[u].x * rw, M[u].y * rw, M[u].z * rw, M[u].w * rw);
             split_st4(buf2, pl_seg, r * ldg + sub * 4, cm);
@@ -1231,6 +1229,11 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
         }
     } else {
         split_layer<0, PD>(voff, wb1, ks1, buf2, pl_hid, ldh, epilogue0, accp);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = tile_lo + hw + u * (NT / 32);
+        if (c < C) stg4(a.closs4 + (size_t)c * F + sub * 4, clv[u]);
     }
     lds_barrier();   // the stage is complete; the global stores drain while the sums are taken
     DSAT_STAMP(a, 3);
