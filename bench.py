@@ -469,6 +469,30 @@ def main():
                 del s3
             except Exception as ex:      # diagnostics only: never fail the bench line
                 result["roofline_sparse"] = {"error": str(ex)}
+        if world == 1 and nflight == 1 and not args.no_profile and sess.split_mask() != 0:
+            # secondary figure, same run, same batch: every MLP on v_mfma_f32_16x16x4_f32 (no product is formed from
+            # bf16 slices) -- the number for a reader who wants the fp32 matrix instruction only; never `value`
+            keys = ("DSAT_P2_SPLIT", "DSAT_P3_SPLIT", "DSAT_P1_A2", "DSAT_P1_BSPLIT")
+            old_env = {k: os.environ.get(k) for k in keys}
+            os.environ.update({k: "0" for k in keys})
+            try:
+                sf = runtime.Session(runtime.Graph(batch, device=dev), wts, max_rounds=args.rounds, device=dev)
+            finally:
+                for k, v in old_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            sf.set_graph_replay(not args.eager)
+            sf.sample(4, args.rounds, seed=7, early_exit=True, want_solved_fraction=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sf.sample(args.steps, args.rounds, seed=8, early_exit=True, want_solved_fraction=False)
+            torch.cuda.synchronize()
+            elf = time.perf_counter() - t1
+            result["fp32_mfma_only"] = {"value": args.steps / elf, "unit": "denoising-steps/s", "ms_per_step": 1e3 * elf / args.steps,
+                                        "split_mask": sf.split_mask()}
+            del sf
         if world == 1 and nflight == 1 and not args.no_profile and args.steps % 2 == 0 and args.config == 2:
             # secondary figure, same run: two independent config-2 batches in flight on two HIP streams
             # (what samples(n) can do when n needs more than one batch); never the headline `value`
