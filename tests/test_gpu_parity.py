@@ -540,3 +540,27 @@ def test_random_batch_structures_match_oracle(rt, seed):
     for gi, (n, _) in enumerate(insts):
         assert np.array_equal(packed[off[gi]:off[gi + 1]], np.packbits(bits[v0:v0 + n], bitorder="little"))
         v0 += n
+
+
+def test_throughput_preference_switches_the_tile_form_not_the_result(rt):
+    """dsat_session_set_throughput: a session told that several batches are in flight runs lit_mlp on 32-row
+    split-product tiles (bit 2 of dsat_session_split_mask); toggling it between steps -- replayed graphs are cached
+    per form -- changes nothing beyond fp32 rounding, and each form is reproducible."""
+    _, batch, data = make_all("medium")
+    ws = oracle_weights(3)
+    rounds = 8
+    d = draws(batch.n_vars, rounds, seed=31)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, dtype=np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.5), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32)["logits"]
+    s = rt.Session(rt.Graph(batch), rt.Weights(ws), max_rounds=rounds)
+    got = {}
+    for i, on in enumerate((False, True, False, True)):
+        s.set_throughput(on)
+        assert bool(s.split_mask() & 4) == on
+        out = s.diffusion_step(0.5, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds, early_exit=False,
+                               want_logits=True)["logits"].cpu().numpy()
+        _close(out, ref, 0, LOGIT_TOL)
+        if on in got:
+            assert np.array_equal(got[on], out)          # the same form, the same bits
+        got[on] = out
