@@ -125,18 +125,30 @@ struct Slab {
 // ---- layout ----------------------------------------------------------------------
 // Input blocks of the first layer of each MLP (concat members of query_sat.py:239,
 // :258, :277) as (logical k, padded k).
-static std::vector<BlockSpec> first_layer_blocks(int mlp) {
+// Concatenation members of an MLP's input: `k` logical columns each, in a slot of `kp` columns of the packed K axis.
+// States, queries, messages and losses are [rows][128] arrays whatever feature_maps / query_maps (<= 128) are:
+// narrower ones sit zero-padded in their 128-column slot, and the matching weight rows are zero.
+static std::vector<BlockSpec> first_layer_blocks(int mlp, int fm = F, int qm = F) {
     switch (mlp) {
         case DSAT_MLP_VARIABLES_QUERY:
         case DSAT_MLP_LIT:
-            return {{F, F}, {AUX_USED, AUX_W}};
+            return {{fm, F}, {AUX_USED, AUX_W}};
         case DSAT_MLP_CLAUSE:
-            return {{F, F}, {F, F}, {F, F}};
+            return {{fm, F}, {qm, F}, {qm, F}};
         case DSAT_MLP_UPDATE_GATE:
-            return {{F, F}, {F, F}, {AUX_USED, AUX_W}, {F, F}, {F, F}};
+            return {{qm, F}, {fm, F}, {AUX_USED, AUX_W}, {qm, F}, {qm, F}};
         default:
-            return {{F, F}};
+            return {{fm, F}};
     }
+}
+// Output columns of an MLP's last layer in the padded layout: {first logical column, count, first padded column}.
+// lit_mlp's [positive | negative] halves and clause_mlp's [variables_loss_all | new_clause_value] are stored to two
+// 128-wide arrays, so the second part starts at padded column 128 (query_sat.py:253, :263-264).
+struct OutPart { int src, n, dst; };
+static std::vector<OutPart> last_layer_parts(int mlp, int fm, int qm, int out_dim) {
+    if (mlp == DSAT_MLP_LIT) return {{0, qm, 0}, {qm, qm, F}};
+    if (mlp == DSAT_MLP_CLAUSE) return {{0, qm, 0}, {qm, fm, F}};
+    return {{0, out_dim, 0}};
 }
 
 static int layer_dims(const dsat_layout* L, int mlp, int layer, int* in_dim, int* out_dim) {
@@ -205,8 +217,8 @@ extern "C" int64_t dsat_layout_blob_floats(const dsat_layout* layout) {
 
 static int check_layout(const dsat_layout* L) {
     DSAT_REQUIRE(L != nullptr, DSAT_E_INVALID, "null layout");
-    DSAT_REQUIRE(L->feature_maps == F && L->query_maps == F, DSAT_E_UNSUPPORTED,
-                 "kernels are built for feature_maps = query_maps = 128 only");
+    DSAT_REQUIRE(L->feature_maps >= 1 && L->feature_maps <= F && L->query_maps >= 1 && L->query_maps <= F, DSAT_E_UNSUPPORTED,
+                 "feature_maps and query_maps must be in 1..128 (narrower states are zero-padded to the kernels' 128-wide rows)");
     DSAT_REQUIRE(L->logit_maps == LOGIT_MAPS, DSAT_E_UNSUPPORTED, "kernels are built for logit_maps = 8 only");
     for (int m = 0; m < DSAT_N_MLP; ++m) {
         DSAT_REQUIRE(L->n_layers[m] >= 2 && L->n_layers[m] <= 4, DSAT_E_UNSUPPORTED,
@@ -464,16 +476,21 @@ static inline void split3_host(float x, uint16_t (&o)[3]) {
 // multiple of 16 along K and N padded to a multiple of 32, zeros elsewhere.
 static void pack_layer(const float* kernel, const float* bias, int in_dim, int out_dim,
                        const std::vector<BlockSpec>& blocks, int npad, int n_off, int kpad, float* wt,
-                       float* bpad) {
+                       float* bpad, const std::vector<OutPart>* parts = nullptr) {
+    const std::vector<OutPart> whole{{0, out_dim, 0}};
+    const std::vector<OutPart>& pp = parts != nullptr ? *parts : whole;
     int src = 0, dst = 0;
     for (const BlockSpec& b : blocks) {
         for (int j = 0; j < b.k; ++j)
-            for (int n = 0; n < out_dim; ++n) wt[(size_t)(n_off + n) * kpad + dst + j] = kernel[(size_t)(src + j) * out_dim + n];
+            for (const OutPart& q : pp)
+                for (int n = 0; n < q.n; ++n)
+                    wt[(size_t)(n_off + q.dst + n) * kpad + dst + j] = kernel[(size_t)(src + j) * out_dim + q.src + n];
         src += b.k;
         dst += b.kp;
     }
     (void)in_dim; (void)npad;
-    for (int n = 0; n < out_dim; ++n) bpad[n_off + n] = bias[n];
+    for (const OutPart& q : pp)
+        for (int n = 0; n < q.n; ++n) bpad[n_off + q.dst + n] = bias[q.src + n];
 }
 
 extern "C" int dsat_weights_load(const float* blob, int64_t n_floats, const dsat_layout* layout,
@@ -510,19 +527,23 @@ extern "C" int dsat_weights_load(const float* blob, int64_t n_floats, const dsat
             const float* kernel = p;
             const float* bias = p + (size_t)in_dim * out_dim;
             p = bias + out_dim;
-            std::vector<BlockSpec> blocks = l == 0 ? first_layer_blocks(m)
+            std::vector<BlockSpec> blocks = l == 0 ? first_layer_blocks(m, layout->feature_maps, layout->query_maps)
                                                     : std::vector<BlockSpec>{{in_dim, round_up(in_dim, 16)}};
+            const bool last = l == layout->n_layers[m] - 1;
+            const std::vector<OutPart> parts = last ? last_layer_parts(m, layout->feature_maps, layout->query_maps, out_dim)
+                                                    : std::vector<OutPart>{{0, out_dim, 0}};
             PackedLayer& pl = w->mlp[m][l];
             pl.in_dim = in_dim;
             pl.out_dim = out_dim;
+            pl.out_ext = parts.back().dst + parts.back().n;
             pl.kpad = 0;
             for (auto& b : blocks) pl.kpad += b.kp;
-            pl.npad = round_up(out_dim, 32);
+            pl.npad = round_up(pl.out_ext, 32);
             Staged s;
             s.dst = &pl;
             s.wt.assign((size_t)pl.npad * pl.kpad, 0.f);
             s.bias.assign(pl.npad, 0.f);
-            pack_layer(kernel, bias, in_dim, out_dim, blocks, pl.npad, 0, pl.kpad, s.wt.data(), s.bias.data());
+            pack_layer(kernel, bias, in_dim, out_dim, blocks, pl.npad, 0, pl.kpad, s.wt.data(), s.bias.data(), &parts);
             staged.push_back(std::move(s));
             if (l == 0 && m <= DSAT_MLP_LIT) { l0_kernel[m] = kernel; l0_bias[m] = bias; }
         }
@@ -533,9 +554,10 @@ extern "C" int dsat_weights_load(const float* blob, int64_t n_floats, const dsat
         w->q_hpad = round_up(qh, 32);
         w->lit_h = lh;
         PackedLayer& pl = w->ql1;
-        auto blocks = first_layer_blocks(DSAT_MLP_VARIABLES_QUERY);
-        pl.in_dim = F + AUX_USED;
+        auto blocks = first_layer_blocks(DSAT_MLP_VARIABLES_QUERY, layout->feature_maps, layout->query_maps);
+        pl.in_dim = layout->feature_maps + AUX_USED;
         pl.out_dim = w->q_hpad + lh;
+        pl.out_ext = pl.out_dim;
         pl.kpad = F + AUX_W;
         pl.npad = w->q_hpad + round_up(lh, 32);
         Staged s;
@@ -868,7 +890,7 @@ static ChainSpec make_chain(const std::vector<PackedLayer>& layers, int rb) {
         c.L[l].kblocks = layers[l].kblocks();
         // column tiles that hold real outputs (npad is rounded to 32 for the per-layer GEMM path;
         // the fragment-ordered weights are tile-major, so trailing all-padding tiles are just not visited)
-        c.L[l].ntiles = (layers[l].out_dim + 15) / 16;
+        c.L[l].ntiles = (layers[l].out_ext + 15) / 16;
         const int cap = std::min(max_tpw_for_rb(rb), ROUND_TPW_CAP);
         c.L[l].tpw = pick_tpw(c.L[l].ntiles, ROUND_NWAVES, cap);
         c.L[l].tpw_half = pick_tpw(c.L[l].ntiles, ROUND_NWAVES / 2, cap);
@@ -935,6 +957,7 @@ static bool plan_round(dsat_session* s) {
     a.vgseg2 = s->n_vchunks > 0 ? s->vgseg2 : nullptr; a.psum2_v = s->psum2_v;
     a.cgseg2 = s->n_cchunks > 0 ? s->cgseg2 : nullptr; a.psum2_c = s->psum2_c;
     a.sel_tab = s->sel_tab; a.n_sel = s->n_sel; a.sel_zero = s->sel_zero;
+    a.inv_f = 1.f / (float)w->layout.feature_maps; a.fm = w->layout.feature_maps;
     a.gj2_three = g->max_clause_len <= 3 && getenv("DSAT_GJ2_FOUR") == nullptr;
     a.vlist = s->vlist_stride > 0 ? s->vmeta4 + s->vlist_at : nullptr; a.vlist_stride = s->vlist_stride; a.vlist_max = s->vlist_max;
     a.clist = s->clist_stride > 0 ? s->vmeta4 + s->clist_at : nullptr; a.clist_stride = s->clist_stride; a.clist_max = s->clist_max;
@@ -1622,8 +1645,8 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
 
     L.run(KC_MISC, [&] { launch_aux(s->aux, N, rounds, s->in_noisy, s->ctl, st); });     // :214-219, :239
     L.run(KC_MISC, [&] { launch_labels(s->labels, N, s->ctl, st); });                    // :145
-    L.run(KC_MISC, [&] { launch_fill(s->V, 1.f, (int64_t)N * F, st); });                 // :148
-    L.run(KC_MISC, [&] { launch_fill(s->Cs, 1.f, (int64_t)C * F, st); });                // :141
+    L.run(KC_MISC, [&] { launch_fill_cols(s->V, 1.f, N, w->layout.feature_maps, st); });   // :148
+    L.run(KC_MISC, [&] { launch_fill_cols(s->Cs, 1.f, C, w->layout.feature_maps, st); });  // :141
 
     for (int r = 0; r < rounds; ++r) {
         const float* auxr = s->aux + (size_t)r * N * AUX_W;
@@ -1668,7 +1691,7 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
         // R10 clause_state = 0.25*PairNorm(new_clause_value) + 0.1*clause_state (+ R18) (:265-266, :348)
         L.run(KC_COLSUM, [&] { launch_colsum(g->cl_seg, g->G, s->nch_c, s->ncv, s->pc, done, st); });
         L.run(KC_PAIRNORM, [&] {
-            launch_pairnorm_apply(g->cl_gid, g->cl_seg, C, s->nch_c, s->ncv, s->pc, s->Cs, 0.25f, 0.1f, 1,
+            launch_pairnorm_apply(1.f / (float)w->layout.feature_maps, g->cl_gid, g->cl_seg, C, s->nch_c, s->ncv, s->pc, s->Cs, 0.25f, 0.1f, 1,
                                   s->Cs, nullptr, done, st);
         });
         if (tapped) tap_copy(tap->clause_state, s->Cs, cf);
@@ -1695,7 +1718,7 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
         // R13 variables = 0.25*PairNorm(new_variables) + 0.1*variables (+ R18)          (:279-280, :347)
         L.run(KC_COLSUM, [&] { launch_colsum(g->var_seg, g->G, s->nch_v, s->newv, s->pv, done, st); });
         L.run(KC_PAIRNORM, [&] {
-            launch_pairnorm_apply(g->var_gid, g->var_seg, N, s->nch_v, s->newv, s->pv, s->V, 0.25f, 0.1f, 1,
+            launch_pairnorm_apply(1.f / (float)w->layout.feature_maps, g->var_gid, g->var_seg, N, s->nch_v, s->newv, s->pv, s->V, 0.25f, 0.1f, 1,
                                   s->V, s->Vlog, done, st);
         });
         if (tapped) tap_copy(tap->variables, s->V, nf);
@@ -2149,6 +2172,8 @@ __global__ void pack_blocks_kernel(const float* __restrict__ x, int in_dim, floa
 }  // namespace dsat
 
 extern "C" int dsat_op_mlp(dsat_session* s, int32_t mlp, const float* x, int32_t rows, float* y, void* stream) {
+    DSAT_REQUIRE(s != nullptr && s->w->layout.feature_maps == F && s->w->layout.query_maps == F, DSAT_E_UNSUPPORTED,
+                 "the single-operator entry points take the released widths (feature_maps = query_maps = 128) only");
     DSAT_REQUIRE(s && x && y, DSAT_E_INVALID, "dsat_op_mlp: null argument");
     DSAT_REQUIRE(mlp >= 0 && mlp < DSAT_N_MLP, DSAT_E_INVALID, "dsat_op_mlp: mlp out of range");
     DSAT_ON_DEVICE(s, "dsat_op_mlp");
@@ -2215,6 +2240,8 @@ extern "C" int dsat_op_mlp_ex(dsat_session* s, int32_t mlp, const float* x, int3
                               int32_t impl, int32_t rb, int32_t nwaves, void* stream) {
     if (impl == 0) return dsat_op_mlp(s, mlp, x, rows, y, stream);
     DSAT_REQUIRE(s && x && y, DSAT_E_INVALID, "dsat_op_mlp_ex: null argument");
+    DSAT_REQUIRE(s->w->layout.feature_maps == F && s->w->layout.query_maps == F, DSAT_E_UNSUPPORTED,
+                 "the single-operator entry points take the released widths (feature_maps = query_maps = 128) only");
     DSAT_REQUIRE(mlp >= 0 && mlp < DSAT_N_MLP, DSAT_E_INVALID, "dsat_op_mlp_ex: mlp out of range");
     DSAT_ON_DEVICE(s, "dsat_op_mlp_ex");
     const int cap = (mlp == DSAT_MLP_CLAUSE) ? std::max(s->g->C, 1) : s->g->N;
@@ -2286,6 +2313,8 @@ extern "C" int dsat_op_literal_gather(dsat_session* s, const float* q, const flo
 }
 
 extern "C" int dsat_op_pair_norm(dsat_session* s, int32_t side, const float* x, float* y, void* stream) {
+    DSAT_REQUIRE(s != nullptr && s->w->layout.feature_maps == F && s->w->layout.query_maps == F, DSAT_E_UNSUPPORTED,
+                 "the single-operator entry points take the released widths (feature_maps = query_maps = 128) only");
     DSAT_REQUIRE(s && x && y, DSAT_E_INVALID, "dsat_op_pair_norm: null argument");
     DSAT_REQUIRE(side == 0 || side == 1, DSAT_E_INVALID, "dsat_op_pair_norm: side must be 0 (variables) or 1 (clauses)");
     DSAT_ON_DEVICE(s, "dsat_op_pair_norm");
@@ -2293,11 +2322,11 @@ extern "C" int dsat_op_pair_norm(dsat_session* s, int32_t side, const float* x, 
     hipStream_t st = (hipStream_t)stream;
     if (side == 0) {
         launch_colsum(g->var_seg, g->G, s->nch_v, x, s->pv, nullptr, st);
-        launch_pairnorm_apply(g->var_gid, g->var_seg, g->N, s->nch_v, x, s->pv, nullptr, 1.f, 0.f, 0, y, nullptr,
+        launch_pairnorm_apply(1.f / (float)F, g->var_gid, g->var_seg, g->N, s->nch_v, x, s->pv, nullptr, 1.f, 0.f, 0, y, nullptr,
                               nullptr, st);
     } else {
         launch_colsum(g->cl_seg, g->G, s->nch_c, x, s->pc, nullptr, st);
-        launch_pairnorm_apply(g->cl_gid, g->cl_seg, g->C, s->nch_c, x, s->pc, nullptr, 1.f, 0.f, 0, y, nullptr,
+        launch_pairnorm_apply(1.f / (float)F, g->cl_gid, g->cl_seg, g->C, s->nch_c, x, s->pc, nullptr, 1.f, 0.f, 0, y, nullptr,
                               nullptr, st);
     }
     DSAT_HIP(hipGetLastError());

@@ -33,6 +33,8 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 // ---- packed dense layer -------------------------------------------------------
 struct PackedLayer {
     int in_dim = 0, out_dim = 0;  // logical Keras dims
+    int out_ext = 0;              // extent of the output columns in the 128-wide padded layout (== out_dim unless the
+                                  // layer's output is a concatenation of parts narrower than 128: see dsat_api.hip)
     int kpad = 0;                 // padded K (sum of padded input blocks)
     int npad = 0;                 // padded N (multiple of 32)
     float* wt = nullptr;          // dev [npad][kpad] = kernel^T, zero padded
@@ -266,6 +268,8 @@ struct RoundArgs {
     const int32_t *vlist, *clist;
     int vlist_stride, vlist_max, clist_stride, clist_max;
     int gj2_three;          // P2: no clause of the batch has more than three literals
+    float inv_f;            // 1 / feature_maps (the per-row variance of PairNorm is over the real features)
+    int fm;                 // feature_maps: state columns [fm, 128) are padding and stay zero
     int a2_tiles;
     const uint4* a2_ws[3];  // lit_mlp's three layers as bf16 slices
     // P2 / P3 with fp32 products formed from bf16 slices (round_p2s_kernel, round_p3s_kernel, split_bf16.h): per
@@ -335,11 +339,12 @@ int colsum_chunks(int G);
 void launch_colsum(const int32_t* seg, int G, int nch, const float* x, float* partial,
                    const int* done, hipStream_t st);
 // v = scale*PairNorm(x) + keep*old ; y_logit (optional) = v ; y_carry = carry ? v*0.2+v*0.8 : v
-void launch_pairnorm_apply(const int32_t* gid, const int32_t* seg, int rows, int nch,
+void launch_pairnorm_apply(float inv_f, const int32_t* gid, const int32_t* seg, int rows, int nch,
                            const float* x, const float* partial, const float* old,
                            float scale, float keep, int carry, float* y_carry, float* y_logit,
                            const int* done, hipStream_t st);
 void launch_fill(float* p, float v, int64_t n, hipStream_t st);
+void launch_fill_cols(float* p, float v, int64_t rows, int cols, hipStream_t st);   // [rows][128]: columns < cols, zero beyond
 void launch_ctl_set(Ctl* dst, const Ctl& val, hipStream_t st);
 void launch_aux(float* aux, int N, int rounds, const float* noisy_num, const Ctl* ctl, hipStream_t st);
 void launch_labels(int32_t* labels, int N, const Ctl* ctl, hipStream_t st);

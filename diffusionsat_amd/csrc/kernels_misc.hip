@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const int32_t* __restrict__
 // y_logit = v ; y_carry = carry ? v*0.2 + v*0.8 : v   (:347-348, forward value of the
 // stop_gradient mix, applied to the state that enters the next round)
 __global__ __launch_bounds__(256) void pairnorm_apply_kernel(
-    const int32_t* __restrict__ gid, const int32_t* __restrict__ seg, int rows, int nch,
+    float inv_f, const int32_t* __restrict__ gid, const int32_t* __restrict__ seg, int rows, int nch,
     const float* __restrict__ x, const float* __restrict__ partial, const float* __restrict__ old,
     float scale, float keep, int carry, float* __restrict__ y_carry, float* __restrict__ y_logit,
     const int* __restrict__ done) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void pairnorm_apply_kernel(
     float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll
     for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);  // within the 32-lane half
-    const float rs = 1.f / sqrtf(ss * (1.f / F) + 1e-6f);
+    const float rs = 1.f / sqrtf(ss * inv_f + 1e-6f);
     float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (old != nullptr) o4 = ld4(old + (size_t)row * F + sub * 4);
     float4 r;
@@ -98,12 +98,12 @@ void launch_colsum(const int32_t* seg, int G, int nch, const float* x, float* pa
     hipLaunchKernelGGL(colsum_kernel, dim3(G, nch), dim3(256), 0, st, seg, nch, x, partial, done);
 }
 
-void launch_pairnorm_apply(const int32_t* gid, const int32_t* seg, int rows, int nch, const float* x,
+void launch_pairnorm_apply(float inv_f, const int32_t* gid, const int32_t* seg, int rows, int nch, const float* x,
                            const float* partial, const float* old, float scale, float keep,
                            int carry, float* y_carry, float* y_logit, const int* done,
                            hipStream_t st) {
     if (rows == 0) return;
-    hipLaunchKernelGGL(pairnorm_apply_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, gid, seg, rows,
+    hipLaunchKernelGGL(pairnorm_apply_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, inv_f, gid, seg, rows,
                        nch, x, partial, old, scale, keep, carry, y_carry, y_logit, done);
 }
 
@@ -118,6 +118,20 @@ void launch_fill(float* p, float v, int64_t n, hipStream_t st) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, v, n);
+}
+
+// [rows][128] rows with `v` in the first `cols` columns and zero in the padding
+__global__ void fill_cols_kernel(float* p, float v, int64_t n, int cols) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = (int)(i & (F - 1)) < cols ? v : 0.f;
+}
+void launch_fill_cols(float* p, float v, int64_t rows, int cols, hipStream_t st) {
+    const int64_t n = rows * F;
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, v, n, cols);
 }
 
 // ---------------------------------------------------------------- control block

@@ -160,7 +160,9 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
                                               const float* __restrict__ psum2, const float* __restrict__ x,
                                               const float* __restrict__ state_in, float* __restrict__ state_out,
                                               bool first, float* sState, int ldS,
-                                              float* sLogit, int ldL, float* sMean, float* sPart, int ldP, int tid) {
+                                              float* sLogit, int ldL, float* sMean, float* sPart, int ldP, int tid,
+                                              float inv_f = 1.f / F, int fm = F) {
+    // inv_f = 1 / feature_maps, fm = feature_maps: narrower states live zero-padded in the 128-wide rows
     // state_in: the carried state of the previous round; state_out: where this round's goes (nullptr:
     // another workgroup normalises the same rows and owns the write).  sMean: F floats; sPart: NT/F rows
     // of F floats, row stride ldP (scratch for the partial sums of the thread groups).
@@ -173,7 +175,8 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
         if (sLogit != nullptr) st4(sLogit + r * ldL + sub * 4, make_float4(0.f, 0.f, 0.f, 0.f));
     }
     if (first) {   // query_sat.py:141, :148: both states start as ones
-        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 one = make_float4(sub * 4 + 0 < fm ? 1.f : 0.f, sub * 4 + 1 < fm ? 1.f : 0.f,
+                                       sub * 4 + 2 < fm ? 1.f : 0.f, sub * 4 + 3 < fm ? 1.f : 0.f);
         for (int r = tile_lo + hw; r < tile_hi; r += NT / 32) {
             st4(sState + (r - tile_lo) * ldS + sub * 4, one);
             if (state_out != nullptr) stg4(state_out + (size_t)r * F + sub * 4, one);
@@ -227,7 +230,7 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
                 float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll
                 for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-                const float rs = 1.f / sqrtf(ss * (1.f / F) + 1e-6f);
+                const float rs = 1.f / sqrtf(ss * inv_f + 1e-6f);
                 const float4 o4 = ov[k];
                 float4 res;
                 res.x = v.x * rs * 0.25f + 0.1f * o4.x; res.y = v.y * rs * 0.25f + 0.1f * o4.y;
@@ -253,7 +256,8 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
 template <int BM>
 __device__ __forceinline__ void tile_colsums(int tile_lo, int rows, const TileMetaDev& tm,
                                              const int32_t* __restrict__ seg, float* __restrict__ psum,
-                                             const float* sT, int ldT, float* sPart, int tid) {
+                                             const float* sT, int ldT, float* sPart, int tid, int fm = F) {
+    // fm = feature_maps: the staged tile only has those columns (the chain has no column tile beyond them)
     const int tile_hi = min(tile_lo + BM, rows);
     if (tile_hi <= tile_lo) return;
     const int c = tid & (F - 1), grp = tid / F;
@@ -267,7 +271,8 @@ __device__ __forceinline__ void tile_colsums(int tile_lo, int rows, const TileMe
         const int len = hi - lo, per = (len + NG - 1) / NG;
         const int a0 = lo + grp * per, a1 = min(a0 + per, hi);
         float sacc = 0.f;
-        for (int r = a0; r < a1; ++r) sacc += sT[(r - tile_lo) * ldT + c];
+        if (c < fm)
+            for (int r = a0; r < a1; ++r) sacc += sT[(r - tile_lo) * ldT + c];
         sPart[tid] = sacc;
         lds_barrier();
         if (tid < F) {
@@ -477,7 +482,7 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
             float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll
             for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-            const float rs = 1.f / sqrtf(ss * (1.f / F) + 1e-6f);
+            const float rs = 1.f / sqrtf(ss * a.inv_f + 1e-6f);
             float4 res;
             res.x = v.x * rs * 0.25f + 0.1f * o4.x; res.y = v.y * rs * 0.25f + 0.1f * o4.y;
             res.z = v.z * rs * 0.25f + 0.1f * o4.z; res.w = v.w * rs * 0.25f + 0.1f * o4.w;
@@ -520,7 +525,7 @@ __device__ __forceinline__ void role_a2(const RoundArgs& a, int tile, const Tile
         load_aux_row(sState + tid * ldS + F, a.aux, n, N, a.round, n < N && !a.tail);
     }
     pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, a.V_out,
-                      a.round == 0, sState, ldS, nullptr, 0, sMean, sPart, F, tid);
+                      a.round == 0, sState, ldS, nullptr, 0, sMean, sPart, F, tid, a.inv_f, a.fm);
     DSAT_STAMP(a, 1);
     DSAT_STAMP(a, 2);
     DSAT_STAMP(a, 3);
@@ -656,7 +661,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
             load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N && !a.tail);
         }
         pairnorm_tile<BM4>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, nullptr,
-                           a.round == 0, sX, ldx, sVlog, ldv, sMean, sMean + F, F, tid);
+                           a.round == 0, sX, ldx, sVlog, ldv, sMean, sMean + F, F, tid, a.inv_f, a.fm);
         auto store_logits = [=](int row, int col, float4 v) {
             int n = tile_lo + row;
             NO_HOIST(n);
@@ -727,7 +732,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
         load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N && !a.tail);
     }
     pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, a.V_out,
-                      a.round == 0, sX, ldx, pair_here ? sVlog : nullptr, ldv, sMean, sMean + F, F, tid);
+                      a.round == 0, sX, ldx, pair_here ? sVlog : nullptr, ldv, sMean, sMean + F, F, tid, a.inv_f, a.fm);
     DSAT_STAMP(a, 1);
 
     if (pair_here) {
@@ -852,7 +857,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
         __syncthreads();
     } else {
         pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.cgseg2, a.psum2_c, a.ncv, a.Cs, a.Cs, a.round == 0, sX, ldx,
-                          nullptr, 0, sMean, sX + F, ldx, tid);   // its barriers also publish sPtr / sIdx
+                          nullptr, 0, sMean, sX + F, ldx, tid, a.inv_f, a.fm);   // its barriers also publish sPtr / sIdx
         // (the partial sums borrow columns 128.. of the tile's first rows, which the gather fills later)
     }
     DSAT_STAMP(a, 1);
@@ -965,7 +970,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
             }
         }, finish);
         DSAT_STAMP(a, 3);
-        tile_colsums<BM>(tile_lo, C, tm, a.cl_seg, a.psum_c_wr, stage, lds, sMean, tid);
+        tile_colsums<BM>(tile_lo, C, tm, a.cl_seg, a.psum_c_wr, stage, lds, sMean, tid, a.fm);
         DSAT_STAMP(a, 4);
         DSAT_STAMP_RT_END(a);
     }
@@ -1050,7 +1055,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
         float* scratch = reinterpret_cast<float*>(buf2);
         constexpr int lds_ = F + 8;
         pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.cgseg2, a.psum2_c, a.ncv, a.Cs, a.Cs, a.round == 0,
-                          scratch, lds_, nullptr, 0, sMean, scratch + BM * lds_, lds_, tid);
+                          scratch, lds_, nullptr, 0, sMean, scratch + BM * lds_, lds_, tid, a.inv_f, a.fm);
 #pragma unroll
         for (int kq = 0; kq < ROWS; ++kq) {
             const int r = hw + kq * (NT / 32);
@@ -1237,7 +1242,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
     }
     lds_barrier();   // the stage is complete; the global stores drain while the sums are taken
     DSAT_STAMP(a, 3);
-    tile_colsums<BM>(tile_lo, C, tm, a.cl_seg, a.psum_c_wr, stage, lds, sMean, tid);
+    tile_colsums<BM>(tile_lo, C, tm, a.cl_seg, a.psum_c_wr, stage, lds, sMean, tid, a.fm);
     DSAT_STAMP(a, 4);
     DSAT_STAMP_RT_END(a);
 }
@@ -1436,7 +1441,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3_kern
             }
         }, finish);
         DSAT_STAMP(a, 2);
-        tile_colsums<BM>(tile_lo, N, tm, a.var_seg, a.psum_v, stage, lds, sPart, tid);
+        tile_colsums<BM>(tile_lo, N, tm, a.var_seg, a.psum_v, stage, lds, sPart, tid, a.fm);
         DSAT_STAMP(a, 3);
         DSAT_STAMP_RT_END(a);
     }
@@ -1657,7 +1662,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
             split_chain<BM / 16, NT, (BM > 16 ? DSAT_SPLIT_PD4 : DSAT_SPLIT_PD1)>(sc, xs, ldx, hA, hB, ldh, wvu, lane, tid, final_store, finish);
         }
         DSAT_STAMP(a, 2);
-        tile_colsums<BM>(tile_lo, N, tm, a.var_seg, a.psum_v, stage, lds, sPart, tid);
+        tile_colsums<BM>(tile_lo, N, tm, a.var_seg, a.psum_v, stage, lds, sPart, tid, a.fm);
         DSAT_STAMP(a, 3);
         DSAT_STAMP_RT_END(a);
     }

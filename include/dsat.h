@@ -18,8 +18,11 @@
  *   - objects live on the HIP device that was current when they were created; a session needs its
  *     graph and weights on one device, and every call on an object must be made with that device
  *     current (hipSetDevice / torch.cuda.device), else it returns DSAT_E_STATE and launches nothing.
- *   - feature_maps = query_maps = 128 only (the reference's defaults,
- *     model/query_sat.py:87-89); other widths return DSAT_E_UNSUPPORTED.
+ *   - feature_maps and query_maps from 1 to 128 (the reference's defaults are 128 / 128,
+ *     model/query_sat.py:87-89): narrower states, queries, messages and losses live zero-padded in the
+ *     kernels' 128-wide rows, so every device buffer of this interface stays [rows][128] and the real
+ *     columns come first.  Wider ones and logit_maps != 8 return DSAT_E_UNSUPPORTED, and the
+ *     single-operator entry points (dsat_op_mlp*, dsat_op_pair_norm) take the released widths only.
  */
 #ifndef DSAT_H
 #define DSAT_H

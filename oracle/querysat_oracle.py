@@ -262,8 +262,11 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
     cmask = np.asarray(data["clauses_mask"])
     w = weights
 
-    clause_state = np.ones((n_clauses, FEATURE_MAPS), dtype=dt)   # :141
-    variables = np.ones((n_vars, FEATURE_MAPS), dtype=dt)          # :148
+    # feature_maps / query_maps as the weights have them (model/query_sat.py:86-89; 128 / 128 in the released model)
+    feature_maps = w["variables_output"][0][0].shape[0]
+    query_maps = w["variables_query"][-1][0].shape[1]
+    clause_state = np.ones((n_clauses, feature_maps), dtype=dt)   # :141
+    variables = np.ones((n_vars, feature_maps), dtype=dt)          # :148
 
     lit_degree = np.asarray(adj.sum(axis=1), dtype=dt).reshape(n2, 1)           # :193
     degree_weight = f(1) / np.sqrt(np.maximum(lit_degree, f(1)))                 # :194
@@ -309,14 +312,14 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
         clauses_loss = clauses_loss * f(4)                           # :248
 
         var_msg = mlp(v1, w["lit_mlp"])                              # :252
-        lit1, lit2 = var_msg[:, :QUERY_MAPS], var_msg[:, QUERY_MAPS:]  # :253
+        lit1, lit2 = var_msg[:, :query_maps], var_msg[:, query_maps:]  # :253
         literals = np.concatenate([lit1, lit2], axis=0)             # :254
         clause_messages = (cl_adj @ literals) * rev_degree_weight   # :255-256
         clause_unit = np.concatenate([clause_state, clause_messages, clauses_loss], axis=-1)  # :258
         clause_data = mlp(clause_unit, w["clause_mlp"])             # :261
 
-        variables_loss_all = clause_data[:, :QUERY_MAPS]            # :263
-        new_clause_value = clause_data[:, QUERY_MAPS:]              # :264
+        variables_loss_all = clause_data[:, :query_maps]            # :263
+        new_clause_value = clause_data[:, query_maps:]              # :264
         if trace:   # pre-normalisation values (the tensors the fused kernels' debug taps expose)
             rec("literals", literals); rec("clauses_loss4", clauses_loss)
             rec("clause_messages", clause_messages)

@@ -102,7 +102,10 @@ def test_weights_load_rejects_bad_blobs(lib):
     blob = np.zeros(10, dtype=np.float32)
     rc = lib.dsat_weights_load(blob.ctypes.data_as(C.c_void_p), 10, C.byref(lay), C.byref(h))
     assert rc == -1 and b"layout needs 856788" in lib.dsat_last_error()
-    lay.feature_maps = 64
+    lay.feature_maps = 64                       # narrower widths are supported: the blob is just too short for them too
+    rc = lib.dsat_weights_load(blob.ctypes.data_as(C.c_void_p), 10, C.byref(lay), C.byref(h))
+    assert rc == -1 and b"layout needs" in lib.dsat_last_error()
+    lay.feature_maps = 256                      # wider than the kernels' 128-wide rows
     rc = lib.dsat_weights_load(blob.ctypes.data_as(C.c_void_p), 10, C.byref(lay), C.byref(h))
     assert rc == -2 and b"128" in lib.dsat_last_error()
 

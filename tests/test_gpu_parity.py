@@ -564,3 +564,37 @@ def test_throughput_preference_switches_the_tile_form_not_the_result(rt):
         if on in got:
             assert np.array_equal(got[on], out)          # the same form, the same bits
         got[on] = out
+
+
+@pytest.mark.parametrize("fm,qm", [(64, 64), (128, 64), (96, 128), (32, 48), (100, 20)])
+def test_other_feature_and_query_widths(rt, fm, qm):
+    """feature_maps / query_maps other than the released 128 / 128 (the reference constructor takes them,
+    model/query_sat.py:86-89, and scales the hidden widths with them, :101-122): states, queries, messages and losses
+    narrower than 128 live zero-padded in the kernels' 128-wide rows, the weights are packed to match, PairNorm's
+    per-row variance is over the real features.  6 rounds of logits against the oracle, fused and per-layer."""
+    from diffusionsat_amd import _lib
+    _, batch, data = make_all("medium")
+    dims = O.mlp_dims(feature_maps=fm, query_maps=qm)
+    lay = _lib.default_layout()
+    lay.feature_maps, lay.query_maps = fm, qm
+    for m, name in enumerate(O.MLP_ORDER):
+        lay.n_layers[m] = len(dims[name]) - 1
+        lay.hidden[m] = dims[name][1]
+    ws = O.make_weights(21, np.float32, bias_scale=0.05, dims=dims)
+    rounds = 6
+    d = draws(batch.n_vars, rounds, seed=19)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, dtype=np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.5), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32, trace=("logits",))
+    for env in ({}, {"DSAT_P3_BM": "32"}, {"DSAT_FUSED": "0"}):
+        os.environ.update(env)
+        try:
+            s = rt.Session(rt.Graph(batch), rt.Weights(ws, lay), max_rounds=rounds)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        out = s.diffusion_step(0.5, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds, early_exit=False,
+                               want_round_logits=True)
+        got = out["round_logits"].cpu().numpy()
+        for r in range(rounds):
+            _close(got[r], ref["trace"]["logits"][r], 0, LOGIT_TOL)
