@@ -81,8 +81,8 @@ class QuerySAT:
                  test_rounds=64, query_maps=128, supervised=True, trial=None, device="cuda:0", seed=0, **kwargs):
         if trial is not None:
             raise NotImplementedError("Optuna trials belong to training (hyperopt.py); not on this path")
-        if feature_maps != 128 or query_maps != 128:
-            raise NotImplementedError("kernels are built for feature_maps = query_maps = 128")
+        if not (1 <= feature_maps <= 128 and 1 <= query_maps <= 128):
+            raise NotImplementedError("the kernels' rows are 128 floats wide: feature_maps and query_maps must be in 1..128")
         self.supervised = supervised
         self.train_rounds, self.test_rounds = train_rounds, test_rounds
         self.feature_maps, self.query_maps, self.vote_layers = feature_maps, query_maps, vote_layers
@@ -91,6 +91,12 @@ class QuerySAT:
         self.device = torch.device(device)
         self.layout = _lib.default_layout()
         self.layout.n_layers[1] = msg_layers          # lit_mlp depth (model/query_sat.py:122)
+        # widths and the hidden sizes that follow from them (model/query_sat.py:101-122: query 1.2 x query_maps,
+        # lit 4 x query_maps, clause 1.6 x, update 1.8 x, output 1 x feature_maps); 128 / 128 gives the defaults
+        self.layout.feature_maps, self.layout.query_maps = int(feature_maps), int(query_maps)
+        for m, h in enumerate((int(query_maps * 1.2), query_maps * 4, int(feature_maps * 1.6), int(feature_maps * 1.8),
+                               int(feature_maps * 1))):
+            self.layout.hidden[m] = h
         self._weights_host: WeightSet = glorot_weights(seed=seed, layout=self.layout)
         self._weights: Optional[runtime.Weights] = None
         self._sessions = {}

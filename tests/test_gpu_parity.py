@@ -598,3 +598,27 @@ def test_other_feature_and_query_widths(rt, fm, qm):
         got = out["round_logits"].cpu().numpy()
         for r in range(rounds):
             _close(got[r], ref["trace"]["logits"][r], 0, LOGIT_TOL)
+
+
+def test_facade_with_narrower_widths(rt):
+    """QuerySAT(feature_maps=64, query_maps=96) through the facade: the constructor derives the hidden widths as the
+    reference does (model/query_sat.py:101-122), and diffusion_step_self matches the oracle run on the same weights."""
+    from diffusionsat_amd.query_sat import GraphInputs, QuerySAT
+    _, batch, data = make_all("3sat")
+    R = 6
+    model = QuerySAT(optimizer=None, test_rounds=R, seed=2, feature_maps=64, query_maps=96)
+    dims = O.mlp_dims(feature_maps=64, query_maps=96)
+    assert [int(model.layout.hidden[m]) for m in range(5)] == [dims[k][1] for k in O.MLP_ORDER]
+    ws = O.make_weights(9, np.float32, bias_scale=0.05, dims=dims)
+    model.set_weights(ws)
+    gi = GraphInputs(batch)
+    n = batch.n_vars
+    d = draws(n, R, seed=3)
+    noisy = O.randomized_rounding(np.full((n, 2), 0.5, dtype=np.float32), d["uniform"])
+    den = np.random.default_rng(1).random((n, 1)).astype(np.float32)
+    out = model.diffusion_step_self(gi, None, None, None, 0.3, _dev(noisy), _dev(den), normal=_dev(d["normal"]),
+                                    labels=_dev(d["labels"]))
+    ref = O.diffusion_step(ws, data, np.float32(0.3), noisy, d["normal"], d["labels"], R, early_exit=True,
+                           dt=np.float32, denoised_num=den)
+    assert int(out["steps_taken"].item()) == ref["steps_taken"]
+    _close(out["prediction"].cpu().numpy(), ref["prediction"], 0, 5e-4)
