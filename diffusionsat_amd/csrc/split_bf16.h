@@ -54,10 +54,10 @@ __device__ __forceinline__ void split_st4(unsigned short* planes, int plane, int
     *reinterpret_cast<uint2*>(planes + 2 * plane + off) = make_uint2(l0, l1);
 }
 
-// The weight ring.  Plain loads one step ahead are enough where four row blocks share a fragment (P2: 384 MFMA
-// cycles per wave and k-step); a 16-row tile has 96 cycles of MFMA work per 3 KiB of weights, is bound by the
-// weight stream and needs several steps in flight -- and hipcc drains every load at a loop's back edge
-// (s_waitcnt vmcnt(0)), so a compiler-scheduled ring degenerates to one step.  Hence the same device as
+// The weight ring.  Plain loads one step ahead were enough for a first version of P2 (four row blocks share a
+// fragment: 384 MFMA cycles per wave and k-step); a 16-row tile has 96 cycles of MFMA work per 3 KiB of weights, is
+// bound by the weight stream and needs several steps in flight -- and hipcc drains every load at a loop's back edge
+// (s_waitcnt vmcnt(0)), so a compiler-scheduled ring degenerates to one step.  Hence, everywhere, the same device as
 // fused_common.h: the loads are inline asm (gload_b128: SGPR base + 32-bit VGPR offset), completion is counted by
 // hand, every wait names the registers it releases, and a slot is refilled only after the last MFMA that reads it
 // (tools/audit_ring.py replays the vmcnt FIFO over the ISA).  A slot = the three slices of one k-step; refills
