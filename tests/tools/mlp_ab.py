@@ -1,6 +1,6 @@
 """A/B of the MLP implementations at config-2 sizes (run on the GPU box)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from diffusionsat_amd import runtime, weights as W, build
 from diffusionsat_amd.batch import make_batch

@@ -1,6 +1,6 @@
 """Run one fused-MLP configuration a few times (for rocprofv3 counter passes)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from diffusionsat_amd import runtime
 from diffusionsat_amd.batch import make_batch

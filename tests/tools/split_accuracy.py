@@ -1,8 +1,9 @@
 """Distance of the per-round logits to the fp64 oracle over a 32-round denoising step, for the three forms the
-round runs in (split-product tiles, fp32-MFMA tiles, per-layer kernels).  GPU box:  python tools/split_accuracy.py"""
+round runs in (split-product tiles, fp32-MFMA tiles, per-layer kernels).  GPU box:  python tests/tools/split_accuracy.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(_TESTS))
+sys.path.insert(0, _TESTS)
 import numpy as np
 import torch
 from oracle import querysat_oracle as O
