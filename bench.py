@@ -334,7 +334,7 @@ def main():
             # f32 in, f32 out, f32 accumulation everywhere; where arithmetic_note says so, an MLP's f32 products are
             # formed exactly-to-f32-rounding from bf16 slices (same tolerances against the f64 oracle as the f32 MFMA)
             "arithmetic_note": ("clause_mlp" if sess.split_mask() & 1 else "") + (" update_gate" if sess.split_mask() & 2 else "")
-                               + (" lit_mlp" if sess.split_mask() & 4 else "")
+                               + (" lit_mlp" if sess.split_mask() & (4 | 32) else "")
                                + (": fp32 products as six bf16-slice products on v_mfma_f32_16x16x32_bf16 (csrc/split_bf16.h); "
                                   "all else v_mfma_f32_16x16x4_f32" if sess.split_mask() else "v_mfma_f32_16x16x4_f32 everywhere"),
             "solved_fraction": solved_fraction,
@@ -391,17 +391,22 @@ def main():
                     ach = fl / (us * 1e-6) / 1e12
                     sp = split.get(k, False)
                     peak = PEAK_SPLIT_F32EQ_TFLOPS if sp else PEAK_MFMA_F32_TFLOPS
-                    a2 = k == "round_p1_var_query_lit" and bool(mask & 4)
-                    if a2:   # lit_mlp as split products on 32-row tiles, the output / query MLPs on the fp32 MFMA:
-                        # the ceiling is the time-weighted mix of the two pipes' peaks (MACs per row: SURVEY.md §8d)
-                        peak = (463_360 + 40_545 + 17_408) / (463_360 / PEAK_SPLIT_F32EQ_TFLOPS + (40_545 + 17_408) / PEAK_MFMA_F32_TFLOPS)
+                    a2 = k == "round_p1_var_query_lit" and bool(mask & (4 | 32))
+                    if a2:   # lit_mlp as split products (32-row tiles: bit 2, 16-row tiles: bit 5), variables_query too when
+                        # bit 3 is set, variables_output on the fp32 MFMA: the ceiling is the time-weighted mix of the two
+                        # pipes' peaks (MACs per row: SURVEY.md §8d)
+                        sp_macs = 463_360 + (40_545 if mask & 8 else 0)
+                        f32_macs = 17_408 + (0 if mask & 8 else 40_545)
+                        peak = (sp_macs + f32_macs) / (sp_macs / PEAK_SPLIT_F32EQ_TFLOPS + f32_macs / PEAK_MFMA_F32_TFLOPS)
                     roofs[k] = {"bound": "mfma", "kernel": kern_name[k].replace("_kernel<4>", "s_kernel").replace("p3_kernel", "p3s_kernel") if sp else kern_name[k],
                                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                 "pipe": ("v_mfma_f32_16x16x32_bf16, six bf16-slice products per fp32 product: achieved = "
                                          "algorithmic fp32 flops / time, peak = dense bf16 MFMA peak %.0f / 6"
                                          % PEAK_MFMA_BF16_TFLOPS) if sp else
-                                        ("lit_mlp: v_mfma_f32_16x16x32_bf16 x6 per fp32 product on 32-row tiles; output / query MLPs: "
-                                         "v_mfma_f32_16x16x4_f32; peak = the two pipes' ceilings weighted by their flops") if a2
+                                        ("lit_mlp%s: v_mfma_f32_16x16x32_bf16 x6 per fp32 product on %d-row tiles; variables_output%s: "
+                                         "v_mfma_f32_16x16x4_f32; peak = the two pipes' ceilings weighted by their flops"
+                                         % (" and variables_query" if mask & 8 else "", 32 if mask & 4 else 16,
+                                            "" if mask & 8 else " / variables_query")) if a2
                                         else "v_mfma_f32_16x16x4_f32",
                                 "traffic": traffic.get(k) if default_cfg2 else None,
                                 "avg_launch_us": us,
@@ -472,7 +477,7 @@ def main():
         if world == 1 and nflight == 1 and not args.no_profile and sess.split_mask() != 0:
             # secondary figure, same run, same batch: every MLP on v_mfma_f32_16x16x4_f32 (no product is formed from
             # bf16 slices) -- the number for a reader who wants the fp32 matrix instruction only; never `value`
-            keys = ("DSAT_P2_SPLIT", "DSAT_P3_SPLIT", "DSAT_P1_A2", "DSAT_P1_BSPLIT")
+            keys = ("DSAT_P2_SPLIT", "DSAT_P3_SPLIT", "DSAT_P1_A2", "DSAT_P1_BSPLIT", "DSAT_P1_ASPLIT")
             old_env = {k: os.environ.get(k) for k in keys}
             os.environ.update({k: "0" for k in keys})
             try:

@@ -706,6 +706,7 @@ struct dsat_session {
     int vlist_stride = 0, vlist_max = 0, clist_stride = 0, clist_max = 0;
     int p1_a2 = 0;          // P1 role A runs on 32-row tiles with split products (role_a2)
     int p1_a2_ok = 0;       // ... is possible for this session (shapes, LDS, role B present)
+    int p1_a1s = 0;         // role A's 16-row tiles run lit_mlp as split products when role B covers every row (role_a1s)
     int p1_a2_env = -1;     // DSAT_P1_A2: 0 never, 1 always, -1 (unset) by batch size / dsat_session_set_throughput
     int pair_blocks = 0;
     // select/SAT workgroups {graph, part, parts, 0}
@@ -1040,6 +1041,10 @@ static bool plan_round(dsat_session* s) {
         // by default only for batches of more than one wave of workgroups, or when the caller asks for throughput
         const bool large = (g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + s->pair_blocks > 256;
         s->p1_a2 = s->p1_a2_ok && (s->p1_a2_env == 1 || (s->p1_a2_env == -1 && large));
+        // 16-row tiles as split products: the same shapes; 57 k cycles per tile against 69 k on the fp32 MFMA
+        // (tools/lit16w_probe.hip).  DSAT_P1_ASPLIT=0 keeps the fp32-MFMA chain.
+        const char* sw3 = getenv("DSAT_P1_ASPLIT");
+        s->p1_a1s = s->p1_a2_ok && !(sw3 != nullptr && sw3[0] == '0');
         r.vmeta2 = s->vmeta4 + s->vmeta2_at;
         for (int l = 0; l < 3 && l < (int)lit.size(); ++l) r.a2_ws[l] = reinterpret_cast<const uint4*>(lit[l].ws);
         if (getenv("DSAT_DEBUG_PLAN") != nullptr) fprintf(stderr, "[dsat] P1 role A on 32-row split tiles: %d\n", s->p1_a2);
@@ -1823,6 +1828,7 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
             a1.pair_blocks = pb_blocks;
             a1.pair_first = pb_first;
         }
+        a1.a1_split = s->p1_a1s && !s->p1_a2 && !a1.tail && a1.pair_first == 0 && a1.pair_blocks == (actN + 63) / 64;
         const int free_cus = 256 - (s->p1_a2 ? a1.a2_tiles : vtiles) - a1.pair_blocks;
         const int cn = (r > 0 && r < rounds && actC > 0 && free_cus >= 8 && !s->no_cn) ? free_cus : 0;
         a1.cn_blocks = cn;
@@ -2413,7 +2419,7 @@ extern "C" int dsat_session_set_throughput(dsat_session* s, int32_t enable) {
 extern "C" int32_t dsat_session_split_mask(const dsat_session* s) {
     if (s == nullptr || !s->use_fused) return 0;
     return (s->p2_split ? 1 : 0) | (s->p3_split ? 2 : 0) | (s->p1_a2 ? 4 : 0) | (s->ra1.sp_ws[0] != nullptr && s->pair_blocks ? 8 : 0) |
-           (s->p3_split && s->p3_bm == 32 ? 16 : 0);
+           (s->p3_split && s->p3_bm == 32 ? 16 : 0) | (s->p1_a1s && !s->p1_a2 ? 32 : 0);
 }
 
 extern "C" int64_t dsat_session_packed_bytes(const dsat_session* s, int32_t* offsets_out) {

@@ -271,6 +271,7 @@ struct RoundArgs {
     float inv_f;            // 1 / feature_maps (the per-row variance of PairNorm is over the real features)
     int fm;                 // feature_maps: state columns [fm, 128) are padding and stay zero
     int a2_tiles;
+    int a1_split;          // role A's 16-row tiles run lit_mlp as split products (role_a1s): role B covers every row
     const uint4* a2_ws[3];  // lit_mlp's three layers as bf16 slices
     // P2 / P3 with fp32 products formed from bf16 slices (round_p2s_kernel, round_p3s_kernel, split_bf16.h): per
     // layer the weights as three bf16 planes in fragment order, k-steps of 32 and column tiles; LDS plan in

@@ -24,6 +24,9 @@
 #ifndef DSAT_SPLIT_PD1
 #define DSAT_SPLIT_PD1 3   // weight k-steps in flight per wave in the 16-row split chains
 #endif
+#ifndef DSAT_SPLIT_PD_A1
+#define DSAT_SPLIT_PD_A1 3   // ... in role A's 16-row lit_mlp
+#endif
 #include "philox.h"
 
 namespace dsat {
@@ -475,22 +478,38 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
         }
         __syncthreads();
         const float4 mean = ld4(sMean + sub * 4);
-        for (int r = lo + hw; r < hi; r += NT / 32) {
-            float4 v = ld4(a.ncv + (size_t)r * F + sub * 4);
-            const float4 o4 = ld4(a.Cs + (size_t)r * F + sub * 4);
-            v.x -= mean.x; v.y -= mean.y; v.z -= mean.z; v.w -= mean.w;
-            float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        // four rows per half-wave in flight: the loop is a chain of dependent round trips otherwise
+        constexpr int UR = 4, STEP = NT / 32;
+        for (int r0 = lo + hw; r0 < hi; r0 += UR * STEP) {
+            float4 v[UR], o4[UR];
 #pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-            const float rs = 1.f / sqrtf(ss * a.inv_f + 1e-6f);
-            float4 res;
-            res.x = v.x * rs * 0.25f + 0.1f * o4.x; res.y = v.y * rs * 0.25f + 0.1f * o4.y;
-            res.z = v.z * rs * 0.25f + 0.1f * o4.z; res.w = v.w * rs * 0.25f + 0.1f * o4.w;
-            res.x = __fadd_rn(__fmul_rn(res.x, 0.2f), __fmul_rn(res.x, 0.8f));
-            res.y = __fadd_rn(__fmul_rn(res.y, 0.2f), __fmul_rn(res.y, 0.8f));
-            res.z = __fadd_rn(__fmul_rn(res.z, 0.2f), __fmul_rn(res.z, 0.8f));
-            res.w = __fadd_rn(__fmul_rn(res.w, 0.2f), __fmul_rn(res.w, 0.8f));
-            stg4(a.Cs + (size_t)r * F + sub * 4, res);
+            for (int u = 0; u < UR; ++u) {
+                const int r = r0 + u * STEP;
+                if (r < hi) {
+                    v[u] = ld4(a.ncv + (size_t)r * F + sub * 4);
+                    o4[u] = ld4(a.Cs + (size_t)r * F + sub * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int r = r0 + u * STEP;
+                if (r < hi) {   // uniform over the half-wave
+                    float4 x = v[u];
+                    x.x -= mean.x; x.y -= mean.y; x.z -= mean.z; x.w -= mean.w;
+                    float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+#pragma unroll
+                    for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+                    const float rs = 1.f / sqrtf(ss * a.inv_f + 1e-6f);
+                    float4 res;
+                    res.x = x.x * rs * 0.25f + 0.1f * o4[u].x; res.y = x.y * rs * 0.25f + 0.1f * o4[u].y;
+                    res.z = x.z * rs * 0.25f + 0.1f * o4[u].z; res.w = x.w * rs * 0.25f + 0.1f * o4[u].w;
+                    res.x = __fadd_rn(__fmul_rn(res.x, 0.2f), __fmul_rn(res.x, 0.8f));
+                    res.y = __fadd_rn(__fmul_rn(res.y, 0.2f), __fmul_rn(res.y, 0.8f));
+                    res.z = __fadd_rn(__fmul_rn(res.z, 0.2f), __fmul_rn(res.z, 0.8f));
+                    res.w = __fadd_rn(__fmul_rn(res.w, 0.2f), __fmul_rn(res.w, 0.8f));
+                    stg4(a.Cs + (size_t)r * F + sub * 4, res);
+                }
+            }
         }
         __syncthreads();
     }
@@ -594,6 +613,89 @@ __device__ __forceinline__ void role_a2(const RoundArgs& a, int tile, const Tile
     DSAT_STAMP(a, 4);
     DSAT_STAMP_RT_END(a);
 }
+
+// ------------------------------------------------------------------------------------- P1, role A on 16 rows, split
+// The same lit_mlp as split products on a 16-ROW tile.  One row block per weight fragment streams 2.85 MB of planes
+// per tile, but the tile still ends sooner than on the fp32 MFMA (tools/lit16w_probe.hip: 57 k cycles against 69 k
+// at 194 workgroups; slicing fp32 weights in registers instead -- 4 B per weight, 36 VALU instructions per fragment
+// -- took 66 k; two column tiles per wave sharing the activation fragments: 56 k in the probe, no change in the
+// kernel).  Used when role B covers every row of the batch (the tile then is PairNorm + lit_mlp only) and
+// role A is not on 32-row tiles.  LDS: h1 [3][16][528] (first the fp32 PairNorm rows) | h2 [3][16][528] | v1 planes
+// [3][16][176] | mean: 116 KB.
+__device__ __forceinline__ void role_a1s(const RoundArgs& a, int tile, const TileMetaDev& tm, float* smem, int tid) {
+    constexpr int BM = 16, PD = DSAT_SPLIT_PD_A1;
+    constexpr int KS0 = (F + AUX_W + 31) / 32, LDX = KS0 * 32 + 16, HID = 512, LD1 = HID + 16;
+    constexpr int KS1 = HID / 32, KS2 = HID / 32;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int N = a.N, NL = a.NL;
+    const int tile_lo = tile * BM;
+    unsigned short* h1 = reinterpret_cast<unsigned short*>(smem);           // [3][16][LD1]
+    unsigned short* h2 = h1 + 3 * BM * LD1;                                 // [3][16][LD1]
+    unsigned short* xs = h2 + 3 * BM * LD1;                                 // v1 planes [3][16][LDX]
+    float* sMean = reinterpret_cast<float*>(xs + 3 * BM * LDX);             // F floats
+    float* sState = smem;                                                   // fp32 rows [16][ldS] inside h1's space
+    constexpr int ldS = F + AUX_W + 8;
+    float* sPart = sState + BM * ldS;                                       // NT / F rows of F floats
+    static_assert((BM * ldS + (NT / F) * F) * 4 <= 3 * BM * LD1 * 2, "PairNorm scratch fits h1");
+    DSAT_STAMP_RT_BEGIN(a);
+    DSAT_STAMP(a, 0);
+    if (tid < BM) {   // aux columns of v1 for this round
+        const int n = tile_lo + tid;
+        load_aux_row(sState + tid * ldS + F, a.aux, n, N, a.round, n < N);
+    }
+    pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, a.V_out,
+                      a.round == 0, sState, ldS, nullptr, 0, sMean, sPart, F, tid, a.inv_f, a.fm);
+    DSAT_STAMP(a, 1);
+    DSAT_STAMP(a, 2);
+    DSAT_STAMP(a, 3);
+    // v1 = [state | aux | zeros up to the last k-step] as slices
+    for (int i = tid; i < BM * (KS0 * 8); i += NT) {
+        const int r = i / (KS0 * 8), c = 4 * (i % (KS0 * 8));
+        const float4 v = c < F + AUX_W ? ld4(sState + r * ldS + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        split_st4(xs, BM * LDX, r * LDX + c, v);
+    }
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff = (unsigned)lane * 16u;
+    const int col4 = 4 * (lane >> 4), row = lane & 15;
+    auto wb = [&](int l, int t, int ks) { return reinterpret_cast<const float4*>(a.a2_ws[l]) + ((size_t)t * ks * 3) * 64; };
+    auto leaky = [](f32x4 acc, float4 b) { return bias_act(acc, b, 1); };
+    float4 b0a = *reinterpret_cast<const float4*>(a.mlit.L[0].bias + wv * 16 + col4);
+    float4 b0b = *reinterpret_cast<const float4*>(a.mlit.L[0].bias + (wv + 16) * 16 + col4);
+    float4 b1a = *reinterpret_cast<const float4*>(a.mlit.L[1].bias + wv * 16 + col4);
+    float4 b1b = *reinterpret_cast<const float4*>(a.mlit.L[1].bias + (wv + 16) * 16 + col4);
+    float4 b2 = *reinterpret_cast<const float4*>(a.mlit.L[2].bias + wv * 16 + col4);
+    asm volatile("" : "+v"(b0a.x), "+v"(b0a.y), "+v"(b0a.z), "+v"(b0a.w), "+v"(b0b.x), "+v"(b0b.y), "+v"(b0b.z), "+v"(b0b.w));
+    asm volatile("" : "+v"(b1a.x), "+v"(b1a.y), "+v"(b1a.z), "+v"(b1a.w), "+v"(b1b.x), "+v"(b1b.y), "+v"(b1b.z), "+v"(b1b.w));
+    asm volatile("" : "+v"(b2.x), "+v"(b2.y), "+v"(b2.z), "+v"(b2.w));
+    const unsigned short* xin = xs + row * LDX + 8 * (lane >> 4);
+    const unsigned short* h1in = h1 + row * LD1 + 8 * (lane >> 4);
+    const unsigned short* h2in = h2 + row * LD1 + 8 * (lane >> 4);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a0a[1] = {z}, a0b[1] = {z}, a1a[1] = {z}, a1b[1] = {z}, a2[1] = {z};
+    // L0 and L1: column tiles wv, then wv + 16; the first barrier also ends the reads of the fp32 rows h1 is about
+    // to overwrite
+    split_layer<1, PD>(voff, wb(0, wv, KS0), KS0, xin, BM * LDX, LDX, [] {}, a0a);
+    split_layer<1, PD, false>(voff, wb(0, wv + 16, KS0), KS0, xin, BM * LDX, LDX, [] {}, a0b);
+    auto ep0 = [&]() {
+        split_st4(h1, BM * LD1, row * LD1 + wv * 16 + col4, leaky(a0a[0], b0a));
+        split_st4(h1, BM * LD1, row * LD1 + (wv + 16) * 16 + col4, leaky(a0b[0], b0b));
+    };
+    split_layer<1, PD>(voff, wb(1, wv, KS1), KS1, h1in, BM * LD1, LD1, ep0, a1a);
+    split_layer<1, PD, false>(voff, wb(1, wv + 16, KS1), KS1, h1in, BM * LD1, LD1, [] {}, a1b);
+    auto ep1 = [&]() {
+        split_st4(h2, BM * LD1, row * LD1 + wv * 16 + col4, leaky(a1a[0], b1a));
+        split_st4(h2, BM * LD1, row * LD1 + (wv + 16) * 16 + col4, leaky(a1b[0], b1b));
+    };
+    split_layer<1, PD>(voff, wb(2, wv, KS2), KS2, h2in, BM * LD1, LD1, ep1, a2);
+    // R6: literals = [lit_mlp(v1)[:, :128] ; [:, 128:]]
+    float* lits = a.lits;
+    const int col = wv * 16 + col4;
+    int n = tile_lo + row;
+    NO_HOIST(n);
+    if (n < N) stg4(lits + ((size_t)(col < F ? n : NL + n)) * F + (col & (F - 1)), bias_act(a2[0], b2, 0));
+    DSAT_STAMP(a, 4);
+    DSAT_STAMP_RT_END(a);
+}
 #endif
 
 // ------------------------------------------------------------------------------------- P1
@@ -628,6 +730,10 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
 #if DSAT_ROUND_NWAVES == 16
     if (roleA && a.a2_tiles > 0) {
         role_a2(a, tile, tm, smem, tid);
+        return;
+    }
+    if (roleA && a.a1_split) {
+        role_a1s(a, tile, tm, smem, tid);
         return;
     }
 #endif

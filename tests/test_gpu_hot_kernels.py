@@ -66,7 +66,7 @@ VARIANTS = ["fused", "fused_a2", "fused_f32mfma", "per_layer"]
 
 def _session(rt, batch, ws, max_rounds, fused):
     env = {"per_layer": {"DSAT_FUSED": "0"}, "fused_a2": {"DSAT_P1_A2": "1", "DSAT_P3_BM": "32"},
-           "fused_f32mfma": {"DSAT_P2_SPLIT": "0", "DSAT_P3_SPLIT": "0", "DSAT_P1_A2": "0", "DSAT_P1_BSPLIT": "0"}}.get(fused, {})
+           "fused_f32mfma": {"DSAT_P2_SPLIT": "0", "DSAT_P3_SPLIT": "0", "DSAT_P1_A2": "0", "DSAT_P1_BSPLIT": "0", "DSAT_P1_ASPLIT": "0"}}.get(fused, {})
     if fused is False:
         env = {"DSAT_FUSED": "0"}
     os.environ.update(env)

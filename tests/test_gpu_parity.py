@@ -514,7 +514,7 @@ def test_random_batch_structures_match_oracle(rt, seed):
                            dt=np.float32, trace=("logits",))
     g = rt.Graph(batch)
     w = rt.Weights(ws)
-    for env in ({}, {"DSAT_P1_A2": "1", "DSAT_P3_BM": "32"}, {"DSAT_P2_SPLIT": "0", "DSAT_P3_SPLIT": "0", "DSAT_P1_A2": "0", "DSAT_P1_BSPLIT": "0"},
+    for env in ({}, {"DSAT_P1_A2": "1", "DSAT_P3_BM": "32"}, {"DSAT_P2_SPLIT": "0", "DSAT_P3_SPLIT": "0", "DSAT_P1_A2": "0", "DSAT_P1_BSPLIT": "0", "DSAT_P1_ASPLIT": "0"},
                 {"DSAT_FUSED": "0"}):
         os.environ.update(env)
         try:
