@@ -191,6 +191,9 @@ def main():
                     help="config 4: instances of the stream each rank processes (the full config is 12 500 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary figures (fp32_mfma_only, throughput_mode): under rocprofv3 they would mix "
+                         "other forms of the same kernels into the per-kernel averages")
     ap.add_argument("--eager", action="store_true", help="disable hipGraph replay")
     ap.add_argument("--batches-in-flight", type=int, default=1,
                     help="opt-in throughput mode: this many independent batches per GPU, each on its own HIP "
@@ -474,7 +477,7 @@ def main():
                 del s3
             except Exception as ex:      # diagnostics only: never fail the bench line
                 result["roofline_sparse"] = {"error": str(ex)}
-        if world == 1 and nflight == 1 and not args.no_profile and sess.split_mask() != 0:
+        if world == 1 and nflight == 1 and not args.no_profile and not args.no_secondary and sess.split_mask() != 0:
             # secondary figure, same run, same batch: every MLP on v_mfma_f32_16x16x4_f32 (no product is formed from
             # bf16 slices) -- the number for a reader who wants the fp32 matrix instruction only; never `value`
             keys = ("DSAT_P2_SPLIT", "DSAT_P3_SPLIT", "DSAT_P1_A2", "DSAT_P1_BSPLIT", "DSAT_P1_ASPLIT")
@@ -498,7 +501,7 @@ def main():
             result["fp32_mfma_only"] = {"value": args.steps / elf, "unit": "denoising-steps/s", "ms_per_step": 1e3 * elf / args.steps,
                                         "split_mask": sf.split_mask()}
             del sf
-        if world == 1 and nflight == 1 and not args.no_profile and args.steps % 2 == 0 and args.config == 2:
+        if world == 1 and nflight == 1 and not args.no_profile and not args.no_secondary and args.steps % 2 == 0 and args.config == 2:
             # secondary figure, same run: two independent config-2 batches in flight on two HIP streams
             # (what samples(n) can do when n needs more than one batch); never the headline `value`
             b2 = make_batch(make_workload(args, 1002 + rank)[0])

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 B="bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-profile"
 rocprofv3 -L > $O/counters_available.txt 2>&1
 grep -c . $O/counters_available.txt
-rocprofv3 --kernel-trace --stats -d $O/stats -o run -- python bench.py --steps 16 --warmup 2 --repeats 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log; echo "stats rc=$?"
+rocprofv3 --kernel-trace --stats -d $O/stats -o run -- python bench.py --steps 16 --warmup 2 --repeats 3 --no-cpu-baseline --no-secondary > $O/bench_under_rocprof.json 2> $O/stats.log; echo "stats rc=$?"
 pass() { n=$1; shift; rocprofv3 --pmc "$@" -d $O/pmc_$n -o runc -- python $B > $O/pmc_$n.json 2> $O/pmc_$n.log; echo "pmc $n rc=$?"; }
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
 pass sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VALU_MFMA_F32

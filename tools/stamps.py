@@ -80,6 +80,8 @@ def table(stamps, meta):
         floor = MFMA_FLOOR[k]
         mask = int(meta.get("split_mask", 0))
         # split-product tiles (csrc/split_bf16.h): six 16-cycle bf16 MFMAs per 32 k-values, busiest SIMD
+        if k == "round_p1" and mask & 32:   # role_a1s: lit_mlp alone, two column tiles per wave in layers 0 and 1
+            floor = (4 * 2 * 5 + 4 * 2 * 16 + 4 * 16) * 6 * 16
         if k == "round_p2" and mask & 1:
             floor = (13 * 12 + 16 * 7) * 6 * 16
         if k == "round_p3" and mask & 2:
