@@ -48,11 +48,14 @@ struct PrefetchDepth { static constexpr int value = TPW >= 6 ? 3 : TPW >= 3 ? DS
 // releases as "+v" operands, so no consumer can be scheduled above it.
 // 16-B load: per-lane 32-bit byte offset (VGPR) + wave-uniform 64-bit base (SGPR pair), so
 // the per-k-block address update is scalar arithmetic and costs no VALU issue slots.
+#ifndef DSAT_WLOAD_POLICY
+#define DSAT_WLOAD_POLICY ""   // cache-policy bits of the weight loads (" nt", " sc1", ...): experiment switch
+#endif
 __device__ __forceinline__ void gload_b128(f32x4& dst, unsigned voff, const float4* sbase) {
 #ifdef DSAT_EXP_NOLOAD
     dst = f32x4{1.f, 2.f, 3.f, (float)voff};
 #else
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" DSAT_WLOAD_POLICY : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 #endif
 }
 // tools/chain_probe.hip defines DSAT_PROBE to time-stamp the phases of a layer
