@@ -403,6 +403,9 @@ def main():
                         peak = (sp_macs + f32_macs) / (sp_macs / PEAK_SPLIT_F32EQ_TFLOPS + f32_macs / PEAK_MFMA_F32_TFLOPS)
                     roofs[k] = {"bound": "mfma", "kernel": kern_name[k].replace("_kernel<4>", "s_kernel").replace("p3_kernel", "p3s_kernel") if sp else kern_name[k],
                                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                # the same algorithmic fp32 flops against the fp32-input MFMA peak (what a kernel that
+                                # keeps v_mfma_f32_16x16x4_f32 is priced on; the round-1 fractions were of this peak)
+                                "frac_of_fp32_mfma_peak": ach / PEAK_MFMA_F32_TFLOPS,
                                 "pipe": ("v_mfma_f32_16x16x32_bf16, six bf16-slice products per fp32 product: achieved = "
                                          "algorithmic fp32 flops / time, peak = dense bf16 MFMA peak %.0f / 6"
                                          % PEAK_MFMA_BF16_TFLOPS) if sp else

@@ -1147,12 +1147,14 @@ static bool plan_round(dsat_session* s) {
             r.s_buf1 = 0;
             r.s_buf2 = x_bytes;
             r.s_bufB = wide ? 0 : x_bytes + h_bytes;
-            r.s_stage = wide ? x_bytes : 0;
+            // the stage must be dead during the LAST layer: that layer reads hB (= X when wide) in a 3-layer chain and
+            // hA in a 2-layer one
+            r.s_stage = wide && r.mupd.nlayers == 3 ? x_bytes : 0;
             r.s_idx = r.s_buf2;
             r.s_idx_cap = ((wide ? 1 : 2) * h_bytes / 4 - 2 * (bm + 8)) / 2;
             r.s_mean = r.s_buf2 + (wide ? 1 : 2) * h_bytes;
             if (wide) r.vmeta = s->vmeta4 + s->vmeta2_at;
-            if (r.s_mean + ROUND_NWAVES * 64 * 4 <= LDS * 4 && bm * (F + 8) * 4 <= (wide ? h_bytes : x_bytes) &&
+            if (r.s_mean + ROUND_NWAVES * 64 * 4 <= LDS * 4 && bm * (F + 8) * 4 <= (r.s_stage != 0 ? h_bytes : x_bytes) &&
                 r.s_idx_cap >= 256) {
                 r.sp_layers = r.mupd.nlayers;
                 for (int l = 0; l < r.mupd.nlayers; ++l) {

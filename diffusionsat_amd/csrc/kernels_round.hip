@@ -516,9 +516,10 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
 }
 
 // ------------------------------------------------------------------------------------- P1, role A on 32 rows
-// lit_mlp (137 -> 512 -> 512 -> 256, query_sat.py:252-254) with fp32 products from bf16 slices (split_bf16.h) pays
-// only with more rows per weight fragment than a 16-row tile has (a 16-row tile as slices is bound by its weight
-// stream, §4.7), and two 512-wide hidden tiles of 32 rows (100 KB each as three planes) do not fit LDS.  So layer 1
+// lit_mlp (137 -> 512 -> 512 -> 256, query_sat.py:252-254) with fp32 products from bf16 slices (split_bf16.h) on
+// two row blocks per weight fragment: a 16-row tile as slices is bound by its weight stream (role_a1s below, §4.7),
+// a 32-row tile does twice the rows in about the same time.  Two 512-wide hidden tiles of 32 rows (100 KB each as
+// three planes) do not fit LDS, so layer 1
 // is computed in two column halves and layer 2 accumulates over the matching halves of its K range:
 //   L0 (two passes of 16 column tiles) -> h1 | L1 cols 0-255 -> h2 | L2 k 0-255 | L1 cols 256-511 -> h2 | L2 k 256-511
 // LDS: h1 [3][32][528] (first the fp32 PairNorm rows) + max(v1 planes [3][32][176], h2 half [3][32][272]) = 150 KB.

@@ -7,6 +7,7 @@ is ~5e-6 (tests/test_oracle.py), so these tests hold the HIP path to 2e-4 abs on
 Discrete outputs (argmin map, rounded bits) are compared only where the oracle's
 pre-threshold margin exceeds the tolerance.
 """
+import os
 import numpy as np
 import pytest
 
@@ -438,7 +439,8 @@ def test_objects_are_bound_to_their_device(rt):
                                            ((40, 64, 48, 72, 24), (3, 3, 3, 3, 2)),
                                            ((64, 96, 256, 256, 32), (2, 2, 2, 2, 2)),     # 16 column tiles, 2-layer update
                                            ((64, 96, 17, 33, 32), (2, 2, 2, 3, 2))])      # narrow split layers
-def test_other_layer_counts_and_hidden_widths(rt, hidden, layers):
+@pytest.mark.parametrize("wide", [False, True])
+def test_other_layer_counts_and_hidden_widths(rt, hidden, layers, wide):
     """The reference constructor derives layer counts and hidden widths from its arguments
     (model/query_sat.py:101-122: msg_layers, the *_scale factors).  Anything but the released shapes leaves
     the compile-time-blocked chains and runs the generic per-layer weight-streaming path (and, for P1,
@@ -459,15 +461,22 @@ def test_other_layer_counts_and_hidden_widths(rt, hidden, layers):
     noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, dtype=np.float32), d["uniform"])
     ref = O.diffusion_step(ws, data, np.float32(0.5), noisy, d["normal"], d["labels"], rounds, early_exit=False,
                            dt=np.float32, trace=("logits",))
-    s = rt.Session(rt.Graph(batch), rt.Weights(ws, lay), max_rounds=rounds)
+    # wide: P3 on 32-row tiles where the layout allows the split-product tile (what large batches run); a 2-layer
+    # update MLP then reads its only hidden tile in the last layer, so the stage of the column sums must be elsewhere
+    env = {"DSAT_P3_BM": "32", "DSAT_P1_A2": "1"} if wide else {}
+    os.environ.update(env)
+    try:
+        s = rt.Session(rt.Graph(batch), rt.Weights(ws, lay), max_rounds=rounds)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    if wide and hidden == (64, 96, 256, 256, 32):
+        assert s.split_mask() & 16          # the 2-layer update MLP does run on the 32-row split-product tile
     out = s.diffusion_step(0.5, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds, early_exit=False,
                            want_round_logits=True)
     got = out["round_logits"].cpu().numpy()
     for r in range(rounds):
         _close(got[r], ref["trace"]["logits"][r], 0, LOGIT_TOL)
-
-
-import os
 
 
 def _fuzz_instances(seed):
