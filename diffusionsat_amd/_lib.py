@@ -101,6 +101,11 @@ def load():
         raise RuntimeError(
             "diffusionsat_amd: HIP extension %s is missing. Build it with "
             "`python -m diffusionsat_amd.build` (needs hipcc); there is no CPU fallback." % LIB_PATH)
+    # PyTorch first: it ships its own HIP runtime, and a process must end up with ONE -- if libdsat.so pulled in
+    # /opt/rocm's copy before torch loaded its own, HIP calls from the extension later found no device
+    # ("hipErrorNoDevice" in a build()-then-smoke() process).  Loaded after torch, the extension binds to the
+    # runtime torch uses (same soname), which is also what makes torch's streams and pointers valid in it.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
