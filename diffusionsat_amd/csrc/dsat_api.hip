@@ -706,6 +706,8 @@ struct dsat_session {
     int vlist_stride = 0, vlist_max = 0, clist_stride = 0, clist_max = 0;
     int p1_a2 = 0;          // P1 role A runs on 32-row tiles with split products (role_a2)
     int p1_a2_ok = 0;       // ... is possible for this session (shapes, LDS, role B present)
+    int prefer_tp = 0;      // dsat_session_set_throughput: several batches in flight, CU-cycles count
+    int p3_part = 0;        // P2's role D forms update_gate's `variables` partial product for P3 (when CUs are free)
     int p1_a1s = 0;         // role A's 16-row tiles run lit_mlp as split products when role B covers every row (role_a1s)
     int p1_a2_env = -1;     // DSAT_P1_A2: 0 never, 1 always, -1 (unset) by batch size / dsat_session_set_throughput
     int pair_blocks = 0;
@@ -1163,6 +1165,12 @@ static bool plan_round(dsat_session* s) {
                     r.sp_nt[l] = r.mupd.L[l].ntiles;
                 }
                 s->p3_split = 1;
+                // role D of P2 (kernels_round.hip): needs the split-product P2 tile's kernel, whole k-steps for the
+                // `variables` columns, and the per-layer path's hidden buffer of update_gate as the partial sums' home
+                const char* ep = getenv("DSAT_P3_PART");
+                s->p3_part = s->p2_split && !(ep != nullptr && ep[0] == '0') && F % 32 == 0 &&
+                             s->hid_ld[DSAT_MLP_UPDATE_GATE] >= 16 * r.sp_nt[0] && r.sp_nt[0] <= ROUND_NWAVES &&
+                             3 * 64 * (F + 16) * 2 <= LDS * 4;
             }
         }
         if (s->p3_bm == 32 && !s->p3_split) ok = false;   // the tables were built for 32-row producer tiles
@@ -1859,6 +1867,24 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         }
         a3.round = r;
         a3.V = a1.V_out;                    // the state P1 of this round wrote
+        {   // role D: only on CUs the clause tiles (and the select workgroups) leave idle
+            const int p2_blocks = (actC + 16 * s->p2_rb - 1) / (16 * s->p2_rb) + (a2.s_enable ? (a2.sel_lead > 0 ? a2.sel_lead : a2.n_sel) : 0);
+            // (one 64-row group costs a workgroup 12-15 k cycles, a clause tile lasts ~52 k, select/SAT of a small graph
+            // ~28 k: the select workgroups take groups too unless they are the long parts of a large graph)
+            const int nd = (actN + 63) / 64, free_cus = 256 - p2_blocks;
+            const int sel_workers = a2.s_enable && a2.sel_lead == 0 ? a2.n_sel : 0;
+            const int extra_blocks = std::min(std::max(nd - sel_workers, 1), std::max(free_cus, 0));
+            const bool part = s->p3_part && !s->prefer_tp && s->p2_rb == 4 && free_cus >= 8 && nd <= 3 * extra_blocks + sel_workers;
+            a2.d_blocks = part ? extra_blocks : 0;
+            a2.d_sel = part && sel_workers > 0;
+            a2.d_workers = part ? sel_workers + extra_blocks : 0;
+            a2.V = a1.V_out;
+            a2.d_ws = s->ra3.sp_ws[0];
+            a2.d_ks0 = s->ra3.sp_ks[0];
+            a2.d_nt0 = s->ra3.sp_nt[0];
+            a2.upd_part = a3.upd_part = part ? s->hid[DSAT_MLP_UPDATE_GATE][0] : nullptr;
+            a2.upd_ld = a3.upd_ld = s->hid_ld[DSAT_MLP_UPDATE_GATE];
+        }
         const bool tapped = tap != nullptr && r == tap->round;
         a2.tap_cmsg = tapped ? tap->clause_messages : nullptr;
         a3.tap_grad = tapped ? tap->variables_grad : nullptr;
@@ -1914,7 +1940,7 @@ static int run_step(dsat_session* s, hipStream_t st, int rounds, int early_exit,
         DSAT_HIP(hipGetLastError());
         return DSAT_OK;
     }
-    auto key = std::make_tuple(rounds, early_exit, mode, s->use_fused + 2 * s->p1_a2);
+    auto key = std::make_tuple(rounds, early_exit, mode, s->use_fused + 2 * s->p1_a2 + 4 * s->prefer_tp);
     auto it = s->graphs.find(key);
     if (it == s->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -2411,6 +2437,7 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t* __restric
 
 extern "C" int dsat_session_set_throughput(dsat_session* s, int32_t enable) {
     DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_throughput: null session");
+    s->prefer_tp = enable != 0;   // (role D of P2 spends CU-cycles to shorten one batch's P3: off when batches overlap)
     if (s->p1_a2_env == -1) {
         const bool large = (s->g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + s->pair_blocks > 256;
         s->p1_a2 = s->p1_a2_ok && (enable != 0 || large);
@@ -2421,7 +2448,7 @@ extern "C" int dsat_session_set_throughput(dsat_session* s, int32_t enable) {
 extern "C" int32_t dsat_session_split_mask(const dsat_session* s) {
     if (s == nullptr || !s->use_fused) return 0;
     return (s->p2_split ? 1 : 0) | (s->p3_split ? 2 : 0) | (s->p1_a2 ? 4 : 0) | (s->ra1.sp_ws[0] != nullptr && s->pair_blocks ? 8 : 0) |
-           (s->p3_split && s->p3_bm == 32 ? 16 : 0) | (s->p1_a1s && !s->p1_a2 ? 32 : 0);
+           (s->p3_split && s->p3_bm == 32 ? 16 : 0) | (s->p1_a1s && !s->p1_a2 ? 32 : 0) | (s->p3_part && !s->prefer_tp ? 64 : 0);
 }
 
 extern "C" int64_t dsat_session_packed_bytes(const dsat_session* s, int32_t* offsets_out) {

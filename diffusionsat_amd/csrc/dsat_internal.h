@@ -272,6 +272,13 @@ struct RoundArgs {
     int fm;                 // feature_maps: state columns [fm, 128) are padding and stay zero
     int a2_tiles;
     int a1_split;          // role A's 16-row tiles run lit_mlp as split products (role_a1s): role B covers every row
+    // update_gate's layer 0 is linear in its inputs and 4 of its 17 k-steps read only the carried state: extra
+    // workgroups of P2 (role D, on CUs its tiles leave idle) form that partial product on 64-row tiles; P3 starts its
+    // accumulators from it and skips those k-steps.  P2: d_blocks > 0, d_ws = update_gate layer 0 as planes,
+    // upd_part = out; P3: upd_part != nullptr = in.
+    int d_blocks, d_workers, d_sel, d_ks0, d_nt0, upd_ld;   // d_sel: the select workgroups are workers 0 .. n_sel-1
+    const uint4* d_ws;
+    float* upd_part;
     const uint4* a2_ws[3];  // lit_mlp's three layers as bf16 slices
     // P2 / P3 with fp32 products formed from bf16 slices (round_p2s_kernel, round_p3s_kernel, split_bf16.h): per
     // layer the weights as three bf16 planes in fragment order, k-steps of 32 and column tiles; LDS plan in

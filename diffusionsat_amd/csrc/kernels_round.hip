@@ -1094,6 +1094,48 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
 // with 13 tiles (the released 204-wide layer) waves 12-15 take one row block of tile 12 each, as chain_static's
 // MIX0 does.  Weight fragments are plain loads one k-step ahead (the compiler counts vmcnt here).
 #if DSAT_ROUND_NWAVES == 16
+// ------------------------------------------------------------------------------------- P2, role D
+// update_gate's layer 0 (query_sat.py:277-278) is linear in unit = [grad | variables | aux | loss_pos | loss_neg],
+// and the k-steps that read `variables` (columns 128..255: k-steps 4..7 of 17) depend on nothing P2 or P3 compute.
+// A 16-row P3 tile is bound by its weight stream, so these workgroups -- on the CUs the clause
+// tiles leave idle, 64 rows per weight fragment -- form  variables @ W0[128:256, :]  once per round, and P3 starts
+// its accumulators from it and streams 13 k-steps instead of 17.  Same slices, same k order inside the partial sum.
+__device__ __forceinline__ void role_d(const RoundArgs& a, int blk, float* smem, int tid) {
+    constexpr int BM = 64, KS = F / 32, LD = F + 16, GAP_AT = F / 32;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int N = a.N;
+    unsigned short* xp = reinterpret_cast<unsigned short*>(smem);   // [3][64][LD]
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff = (unsigned)lane * 16u;
+    const int col4 = 4 * (lane >> 4), row = lane & 15;
+    const unsigned short* xin = xp + row * LD + 8 * (lane >> 4);
+    const float4* wb = reinterpret_cast<const float4*>(a.d_ws) + ((size_t)(wv < a.d_nt0 ? wv : 0) * a.d_ks0 + GAP_AT) * 3 * 64;
+    // the 64-row groups are dealt round-robin to the d_workers workgroups: the d_blocks extra ones and, behind their
+    // own work, the select/SAT workgroups (a third of a tile's time at 20k nodes)
+    for (int lo = blk * BM; lo < N; lo += a.d_workers * BM) {
+        for (int i = tid; i < BM * (F / 4); i += NT) {
+            const int r = i / (F / 4), c = 4 * (i % (F / 4));
+            const float4 v = lo + r < N ? ld4(a.V + (size_t)(lo + r) * F + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            split_st4(xp, BM * LD, r * LD + c, v);
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wv < a.d_nt0) {
+            split_layer<4, DSAT_SPLIT_PD4>(voff, wb, KS, xin, BM * LD, LD, [] {}, acc);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                int n = lo + rb * 16 + row;
+                NO_HOIST(n);
+                if (n < N) stg4(a.upd_part + (size_t)n * a.upd_ld + wv * 16 + col4, make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]));
+            }
+        } else {
+            split_layer<0, DSAT_SPLIT_PD4>(voff, nullptr, 0, nullptr, 0, 0, [] {}, reinterpret_cast<f32x4(&)[1]>(acc[0]));
+        }
+        lds_barrier();   // every wave is done with the planes before the next group's rows overwrite them
+    }
+}
+
 __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     constexpr int RB = 4, BM = 16 * RB;
@@ -1124,6 +1166,12 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
     }
     if (both_arrived(done, tm) != 0) return;
     if (extra) {
+        // role D: the last d_blocks blocks of the grid (they are `extra` blocks: behind the tiles)
+        const int dblk = (int)blockIdx.x - ((int)gridDim.x - a.d_blocks);
+        if (a.d_blocks > 0 && dblk >= 0) {
+            role_d(a, a.d_workers - a.d_blocks + dblk, smem, tid);
+            return;
+        }
         DSAT_STAMP_RT_BEGIN(a);
         DSAT_STAMP(a, 0);
         select_sat_body<NT>(sel_blk, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
@@ -1131,6 +1179,10 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
                             smem);
         DSAT_STAMP(a, 4);
         DSAT_STAMP_RT_END(a);
+        if (a.d_sel != 0 && sel_blk < a.n_sel) {   // ... then this workgroup's share of role D
+            __syncthreads();
+            role_d(a, sel_blk, smem, tid);
+        }
         return;
     }
     unsigned char* sbytes = reinterpret_cast<unsigned char*>(smem);
@@ -1598,6 +1650,16 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
             wv[u] = a.vdeg_w[v];
         }
     }
+    // ... and with the start values of update_gate's layer 0 (role D of P2 formed the `variables` k-steps): this lane's
+    // four columns of its wave's column tile, row l & 15 of each row block
+    float4 upd0[BM / 16];
+#pragma unroll
+    for (int rb = 0; rb < BM / 16; ++rb) {
+        upd0[rb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int n = tile_lo + rb * 16 + (lane & 15);
+        if (a.upd_part != nullptr && wave < a.sp_nt[0] && n < N)
+            upd0[rb] = ld4(a.upd_part + (size_t)n * a.upd_ld + wave * 16 + 4 * (lane >> 4));
+    }
     if (both_arrived(done, tm) != 0) return;
     if (a.sel_zero && blockIdx.x == 0)   // multi-part select adds its counts up: start the next one from zero
         for (int g = tid; g < a.G; g += NT) a.graph_unsat[g] = 0;
@@ -1766,7 +1828,12 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
             sc.nlayers = a.sp_layers;
 #pragma unroll
             for (int l = 0; l < 3; ++l) sc.L[l] = SplitLayer{a.sp_ws[l], a.mupd.L[l].bias, a.sp_ks[l], a.sp_nt[l]};
-            split_chain<BM / 16, NT, (BM > 16 ? DSAT_SPLIT_PD4 : DSAT_SPLIT_PD1)>(sc, xs, ldx, hA, hB, ldh, wvu, lane, tid, final_store, finish);
+            if (a.upd_part != nullptr) {   // the `variables` k-steps of layer 0 were formed by P2's role D
+                sc.init = a.upd_part;
+                sc.gap_at = OFF_V / 32;
+                sc.gap_len = F / 32;
+            }
+            split_chain<BM / 16, NT, (BM > 16 ? DSAT_SPLIT_PD4 : DSAT_SPLIT_PD1)>(sc, xs, ldx, hA, hB, ldh, wvu, lane, tid, final_store, finish, upd0);
         }
         DSAT_STAMP(a, 2);
         tile_colsums<BM>(tile_lo, N, tm, a.var_seg, a.psum_v, stage, lds, sPart, tid, a.fm);
@@ -2011,7 +2078,7 @@ hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {
     if (tiles == 0) return hipSuccess;
 #if DSAT_ROUND_NWAVES == 16
     if (rb == 4 && a.sp_ws[0] != nullptr) {
-        hipLaunchKernelGGL(round_p2s_kernel, dim3(tiles), dim3(NT), 0, st, a);
+        hipLaunchKernelGGL(round_p2s_kernel, dim3(tiles + a.d_blocks), dim3(NT), 0, st, a);
         return hipGetLastError();
     }
 #endif

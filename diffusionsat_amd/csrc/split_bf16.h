@@ -64,14 +64,19 @@ __device__ __forceinline__ void split_st4(unsigned short* planes, int plane, int
 // are clamped to the last step, so exactly 3*PD loads are in flight at every wait of the main loop.
 struct SplitSlot { sf32x4 h, m, l; };
 
+// A layer may skip a run of k-steps (`gap_len` steps from step `gap_at` on: their products were formed elsewhere and
+// enter through the accumulators' start value): step j of the `stot` executed ones is k-step j + (j >= gap_at ?
+// gap_len : 0) of the weight image and of the activation planes.
+__device__ __forceinline__ int split_kstep(int j, int gap_at, int gap_len) { return j + (j >= gap_at ? gap_len : 0); }
+
 template <int PD, int P0 = 0, int P1 = PD>   // slots [P0, P1): the prime may be issued in two parts, in slot order
 __device__ __forceinline__ void split_prime(SplitSlot (&ring)[PD], unsigned voff, const float4* __restrict__ wbase,
-                                            int stot) {
+                                            int stot, int gap_at = 0, int gap_len = 0) {
     static_assert(3 * PD <= 63, "vmcnt field is 6 bits");
     const int last = stot - 1;
 #pragma unroll
     for (int p = P0; p < P1; ++p) {
-        const float4* sb = wbase + (size_t)(p < last ? p : last) * 192;
+        const float4* sb = wbase + (size_t)split_kstep(p < last ? p : last, gap_at, gap_len) * 192;
         gload_b128(ring[p].h, voff, sb);
         gload_b128(ring[p].m, voff, sb + 64);
         gload_b128(ring[p].l, voff, sb + 128);
@@ -130,12 +135,12 @@ __device__ __forceinline__ void split_rotate_prio(int step) {
 template <int NRB, int PD>
 __device__ __forceinline__ void split_ring_steps(SplitSlot (&ring)[PD], unsigned voff, const float4* __restrict__ wbase,
                                                  int s0, int s1, int stot, const unsigned short* px, int plane, int ld,
-                                                 int sbuf0, sf32x4 (&acc)[NRB]) {
+                                                 int sbuf0, sf32x4 (&acc)[NRB], int gap_at = 0, int gap_len = 0) {
     const int last = stot - 1;
     for (int s = s0; s < s1; s += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
-            const unsigned short* q = px + (s + p - sbuf0) * 32;
+            const unsigned short* q = px + (split_kstep(s + p, gap_at, gap_len) - sbuf0) * 32;
             split_rotate_prio(s + p);
             const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q), xm = *reinterpret_cast<const bf16x8*>(q + plane),
                          xl = *reinterpret_cast<const bf16x8*>(q + 2 * plane);
@@ -144,7 +149,7 @@ __device__ __forceinline__ void split_ring_steps(SplitSlot (&ring)[PD], unsigned
             split_step<NRB>(ring[p], xh, xm, xl, q, plane, ld, acc);
             __builtin_amdgcn_sched_barrier(0);
             const int sn = s + p + PD;
-            const float4* sb = wbase + (size_t)(sn < last ? sn : last) * 192;
+            const float4* sb = wbase + (size_t)split_kstep(sn < last ? sn : last, gap_at, gap_len) * 192;
             gload_b128(ring[p].h, voff, sb);
             gload_b128(ring[p].m, voff, sb + 64);
             gload_b128(ring[p].l, voff, sb + 128);
@@ -155,7 +160,8 @@ __device__ __forceinline__ void split_ring_steps(SplitSlot (&ring)[PD], unsigned
 // The last stot - s1 (< PD) steps, already in slots 0.. when the main loop ended; drains the queue.
 template <int NRB, int PD>
 __device__ __forceinline__ void split_ring_tail(SplitSlot (&ring)[PD], int s1, int stot, const unsigned short* px,
-                                                int plane, int ld, int sbuf0, sf32x4 (&acc)[NRB]) {
+                                                int plane, int ld, int sbuf0, sf32x4 (&acc)[NRB], int gap_at = 0,
+                                                int gap_len = 0) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0].h), "+v"(ring[0].m), "+v"(ring[0].l) :: "memory");
 #ifndef DSAT_SPLIT_NO_ROTPRIO
     __builtin_amdgcn_s_setprio(0);
@@ -165,7 +171,7 @@ __device__ __forceinline__ void split_ring_tail(SplitSlot (&ring)[PD], int s1, i
 #pragma unroll
     for (int p = 0; p + 1 < PD; ++p) {
         if (s1 + p < stot) {
-            const unsigned short* q = px + (s1 + p - sbuf0) * 32;
+            const unsigned short* q = px + (split_kstep(s1 + p, gap_at, gap_len) - sbuf0) * 32;
             const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q), xm = *reinterpret_cast<const bf16x8*>(q + plane),
                          xl = *reinterpret_cast<const bf16x8*>(q + 2 * plane);
             split_step<NRB>(ring[p], xh, xm, xl, q, plane, ld, acc);
@@ -269,12 +275,21 @@ __device__ __forceinline__ void pin_bias(float4 (&v)[3]) {
     for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
 }
 struct SplitLayer { const uint4* ws; const float* bias; int ksteps, ntiles; };
-struct SplitChain { SplitLayer L[3]; int nlayers; };
+struct SplitChain {
+    SplitLayer L[3];
+    int nlayers;
+    // layer 0 may start from partial sums formed elsewhere (`init` != nullptr: the caller passes this lane's values as
+    // `start`): the products of k-steps [gap_at, gap_at + gap_len), which the layer then skips
+    const float* init = nullptr;
+    int gap_at = 0, gap_len = 0;
+};
 
 template <int NRB, int NTHREADS, int PD, typename Store, typename Prep>
 __device__ __forceinline__ void split_chain(const SplitChain& m, const unsigned short* in, int ld_in,
                                             unsigned short* hA, unsigned short* hB, int ldh, int wv, int lane,
-                                            int tid, Store&& final_store, Prep&& prep) {
+                                            int tid, Store&& final_store, Prep&& prep, const float4* start = nullptr) {
+    // start: NRB float4 in the caller's registers -- m.init's values for this lane (row rb * 16 + (lane & 15), columns
+    // wv * 16 + 4 * (lane >> 4) .. + 3), requested early enough that their latency is hidden
     constexpr int ROWS = 16 * NRB;
     const int col4 = 4 * (lane >> 4);
     bool on[3];
@@ -291,12 +306,20 @@ __device__ __forceinline__ void split_chain(const SplitChain& m, const unsigned 
 #pragma unroll
     for (int l = 0; l < 3; ++l)
         wb[l] = reinterpret_cast<const float4*>(m.L[l < m.nlayers ? l : 0].ws) + ((size_t)(on[l] ? wv : 0) * m.L[l < m.nlayers ? l : 0].ksteps * 3) * 64;
+    // layer 0's start values: already in registers (the caller loaded them early), or zeros
+    float4 iv[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) iv[rb] = m.init != nullptr && start != nullptr ? start[rb] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int g_at = m.init != nullptr ? m.gap_at : 0, g_len = m.init != nullptr ? m.gap_len : 0;
+    const int ks0 = m.L[0].ksteps - g_len;   // executed k-steps of layer 0
     pin_bias(bv);   // the biases are ordinary loads: complete them before the asm loads start
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) asm volatile("" : "+v"(iv[rb].x), "+v"(iv[rb].y), "+v"(iv[rb].z), "+v"(iv[rb].w));
     // the first layer's prime in two parts: the registers prep() still holds (a gather's sums) cap what fits before it
     constexpr int PRE = PD < 2 ? PD : 2;
-    if (on[0]) split_prime<PD, 0, PRE>(ring, voff, wb[0], m.L[0].ksteps);
+    if (on[0]) split_prime<PD, 0, PRE>(ring, voff, wb[0], ks0, g_at, g_len);
     prep();
-    if (on[0]) split_prime<PD, PRE, PD>(ring, voff, wb[0], m.L[0].ksteps);
+    if (on[0]) split_prime<PD, PRE, PD>(ring, voff, wb[0], ks0, g_at, g_len);
     lds_barrier();
     const unsigned short* src = in;
     int ld = ld_in;
@@ -306,12 +329,14 @@ __device__ __forceinline__ void split_chain(const SplitChain& m, const unsigned 
         const bool last = l + 1 == m.nlayers;
         sf32x4 acc[NRB];
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) acc[rb] = sf32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rb = 0; rb < NRB; ++rb)
+            acc[rb] = l == 0 ? sf32x4{iv[rb].x, iv[rb].y, iv[rb].z, iv[rb].w} : sf32x4{0.f, 0.f, 0.f, 0.f};
         if (on[l]) {
-            const int ks = m.L[l].ksteps, main = ks / PD * PD;
+            const int ks = l == 0 ? ks0 : m.L[l].ksteps, main = ks / PD * PD;
+            const int ga = l == 0 ? g_at : 0, gl = l == 0 ? g_len : 0;
             const unsigned short* px = src + (lane & 15) * ld + 8 * (lane >> 4);
-            split_ring_steps<NRB, PD>(ring, voff, wb[l], 0, main, ks, px, ROWS * ld, ld, 0, acc);
-            split_ring_tail<NRB, PD>(ring, main, ks, px, ROWS * ld, ld, 0, acc);
+            split_ring_steps<NRB, PD>(ring, voff, wb[l], 0, main, ks, px, ROWS * ld, ld, 0, acc, ga, gl);
+            split_ring_tail<NRB, PD>(ring, main, ks, px, ROWS * ld, ld, 0, acc, ga, gl);
         }
         if (!last) {
             if (on[l + 1]) split_prime<PD>(ring, voff, wb[l + 1], m.L[l + 1].ksteps);   // travel during the epilogue
