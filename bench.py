@@ -387,6 +387,10 @@ def main():
             default_cfg2 = args.config == 2 and (args.graphs, args.vars) == (31, 100)
             roofs = {}
             mask = sess.split_mask()
+            if mask & 64:   # role D: P2's extra workgroups form the `variables` part of update_gate's first layer
+                moved = 2.0 * n * 128 * 230          # 128 state columns x 230 hidden units per variable
+                per_launch["round_p3_var_update"] -= moved
+                per_launch["round_p2_clause"] += moved
             split = {"round_p2_clause": bool(mask & 1), "round_p3_var_update": bool(mask & 2)}
             for k, fl in per_launch.items():
                 if k in prof and prof[k]["launches"] > 0:

@@ -1795,6 +1795,25 @@ static void plan_pair_blocks(int n_active, int* first, int* blocks) {
 
 // Fused launch sequence: per round P1 -> [S of the previous round] -> P2 -> P3, then the tail
 // P1 (last round's PairNorm + logits) and the last S.
+// Role D of P2 (kernels_round.hip): how many extra workgroups form update_gate's `variables` partial product for P3
+// (0: not in this launch).  Only on CUs the clause tiles and the select workgroups leave idle; one 64-row group costs
+// a workgroup 12-15 k cycles, a clause tile lasts ~52 k, select/SAT of a small graph ~28 k: the select workgroups
+// take groups too unless they are the long parts of a large graph (sel_lead > 0).
+static int role_d_blocks(const dsat_session* s, int actN, int actC, bool sel_on, int sel_lead, int n_sel, int* workers,
+                         int* dsel) {
+    *workers = 0;
+    *dsel = 0;
+    if (!s->p3_part || s->prefer_tp || s->p2_rb != 4) return 0;
+    const int p2_blocks = (actC + 63) / 64 + (sel_on ? (sel_lead > 0 ? sel_lead : n_sel) : 0);
+    const int nd = (actN + 63) / 64, free_cus = 256 - p2_blocks;
+    const int sel_workers = sel_on && sel_lead == 0 ? n_sel : 0;
+    const int extra_blocks = std::min(std::max(nd - sel_workers, 1), std::max(free_cus, 0));
+    if (free_cus < 8 || nd > 3 * extra_blocks + sel_workers) return 0;
+    *workers = sel_workers + extra_blocks;
+    *dsel = sel_workers > 0;
+    return extra_blocks;
+}
+
 static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int early_exit, float* trace_logits,
                               bool prof, int act_graphs = -1) {
     Launcher L{s, st, prof};
@@ -1868,16 +1887,12 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         a3.round = r;
         a3.V = a1.V_out;                    // the state P1 of this round wrote
         {   // role D: only on CUs the clause tiles (and the select workgroups) leave idle
-            const int p2_blocks = (actC + 16 * s->p2_rb - 1) / (16 * s->p2_rb) + (a2.s_enable ? (a2.sel_lead > 0 ? a2.sel_lead : a2.n_sel) : 0);
-            // (one 64-row group costs a workgroup 12-15 k cycles, a clause tile lasts ~52 k, select/SAT of a small graph
-            // ~28 k: the select workgroups take groups too unless they are the long parts of a large graph)
-            const int nd = (actN + 63) / 64, free_cus = 256 - p2_blocks;
-            const int sel_workers = a2.s_enable && a2.sel_lead == 0 ? a2.n_sel : 0;
-            const int extra_blocks = std::min(std::max(nd - sel_workers, 1), std::max(free_cus, 0));
-            const bool part = s->p3_part && !s->prefer_tp && s->p2_rb == 4 && free_cus >= 8 && nd <= 3 * extra_blocks + sel_workers;
-            a2.d_blocks = part ? extra_blocks : 0;
-            a2.d_sel = part && sel_workers > 0;
-            a2.d_workers = part ? sel_workers + extra_blocks : 0;
+            int workers = 0, dsel = 0;
+            const int extra_blocks = role_d_blocks(s, actN, actC, a2.s_enable != 0, a2.sel_lead, a2.n_sel, &workers, &dsel);
+            const bool part = extra_blocks > 0;
+            a2.d_blocks = extra_blocks;
+            a2.d_sel = dsel;
+            a2.d_workers = workers;
             a2.V = a1.V_out;
             a2.d_ws = s->ra3.sp_ws[0];
             a2.d_ks0 = s->ra3.sp_ks[0];
@@ -2445,10 +2460,15 @@ extern "C" int dsat_session_set_throughput(dsat_session* s, int32_t enable) {
     return DSAT_OK;
 }
 
+static bool role_d_on(const dsat_session* s) {   // for the whole batch, select workgroups riding along
+    int w = 0, d = 0;
+    return role_d_blocks(s, s->g->N, s->g->C, true, s->ra2.sel_lead, s->ra2.n_sel, &w, &d) > 0;
+}
+
 extern "C" int32_t dsat_session_split_mask(const dsat_session* s) {
     if (s == nullptr || !s->use_fused) return 0;
     return (s->p2_split ? 1 : 0) | (s->p3_split ? 2 : 0) | (s->p1_a2 ? 4 : 0) | (s->ra1.sp_ws[0] != nullptr && s->pair_blocks ? 8 : 0) |
-           (s->p3_split && s->p3_bm == 32 ? 16 : 0) | (s->p1_a1s && !s->p1_a2 ? 32 : 0) | (s->p3_part && !s->prefer_tp ? 64 : 0);
+           (s->p3_split && s->p3_bm == 32 ? 16 : 0) | (s->p1_a1s && !s->p1_a2 ? 32 : 0) | (role_d_on(s) ? 64 : 0);
 }
 
 extern "C" int64_t dsat_session_packed_bytes(const dsat_session* s, int32_t* offsets_out) {

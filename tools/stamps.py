@@ -84,8 +84,8 @@ def table(stamps, meta):
             floor = (4 * 2 * 5 + 4 * 2 * 16 + 4 * 16) * 6 * 16
         if k == "round_p2" and mask & 1:
             floor = (13 * 12 + 16 * 7) * 6 * 16
-        if k == "round_p3" and mask & 2:
-            floor = (4 * 17 + 4 * 8 + 2 * 8) * 6 * 16
+        if k == "round_p3" and mask & 2:   # (role D of P2 takes 4 of layer 0's 17 k-steps: bit 6)
+            floor = (4 * (13 if mask & 64 else 17) + 4 * 8 + 2 * 8) * 6 * 16
         kk = {"tiles": int(t.shape[0]), "cycles_per_tile_median": float(np.median(tot)),
               "cycles_per_tile_max": float(tot.max()), "clock_ghz_median": ghz,
               "us_per_tile_median": float(np.median(tot)) / (ghz * 1e3) if ghz == ghz else None,
