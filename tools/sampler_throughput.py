@@ -20,7 +20,7 @@ for k in (1, 2, 3):
     s.samples(1)                      # warm-up: graph capture, first import
     seen = [0]
 
-    def count_only(assignment, solved, counts, need):
+    def count_only(packed, solved, copies, counts, need):
         seen[0] += 1
         return len(solved), len(solved), (0 if seen[0] >= N_BATCHES else need)
 
