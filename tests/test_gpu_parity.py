@@ -575,6 +575,40 @@ def test_throughput_preference_switches_the_tile_form_not_the_result(rt):
         got[on] = out
 
 
+def test_update_gate_partial_sums_from_p2s_idle_cus(rt):
+    """Role D of P2: the `variables` k-steps of update_gate's first layer (model/query_sat.py:277-278)
+    are formed by extra workgroups of P2 and P3 starts its accumulators from them (bit 6 of
+    dsat_session_split_mask).  Off (DSAT_P3_PART=0, or a session told that batches overlap) P3 streams the whole
+    layer itself: another summation order, the same logits to fp32 rounding; a ragged batch whose last 64-row group
+    and last 16-row tile are partial."""
+    _, batch, data = make_all("ragged")
+    ws = oracle_weights(5)
+    rounds = 8
+    d = draws(batch.n_vars, rounds, seed=41)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, dtype=np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.5), noisy, d["normal"], d["labels"], rounds, early_exit=True,
+                           dt=np.float32)
+    outs = {}
+    for env in ({}, {"DSAT_P3_PART": "0"}):
+        os.environ.update(env)
+        try:
+            s = rt.Session(rt.Graph(batch), rt.Weights(ws), max_rounds=rounds)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert bool(s.split_mask() & 64) == (not env)
+        for on in (False, True):      # ... and the session-level switch
+            s.set_throughput(on)
+            assert bool(s.split_mask() & 64) == (not env and not on)
+            out = s.diffusion_step(0.5, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds,
+                                   early_exit=True, want_logits=True)
+            _close(out["logits"].cpu().numpy(), ref["logits"], 0, LOGIT_TOL)
+            assert int(out["steps_taken"].item()) == ref["steps_taken"]
+            outs[(bool(env), on)] = out["logits"].cpu().numpy()
+    # told that batches overlap, both sessions run the same code (no role D, lit_mlp on 32-row tiles): the same bits
+    assert np.array_equal(outs[(True, True)], outs[(False, True)])
+
+
 @pytest.mark.parametrize("fm,qm", [(64, 64), (128, 64), (96, 128), (32, 48), (100, 20)])
 def test_other_feature_and_query_widths(rt, fm, qm):
     """feature_maps / query_maps other than the released 128 / 128 (the reference constructor takes them,
