@@ -1206,17 +1206,11 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
         staged = stage_csr(a.cg_rowptr, a.cg_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr, sIdx,
                            a.s_idx_cap, tid);
     }
-#ifdef DSAT_EXP_P2_NOSTATE
-    if (rows_ready) {
-        __syncthreads();
-    } else {
-#else
     if (rows_ready) {   // R10 was finished by P1's extra blocks: slice the rows loaded above
 #pragma unroll
         for (int kq = 0; kq < ROWS; ++kq) split_st4(buf1, pl_seg, (hw + kq * (NT / 32)) * ldg + sub * 4, srow[kq]);
         __syncthreads();
-    } else {
-#endif   // PairNorm here, in fp32 (buf2 is free: rows, then the thread groups' partial sums), then the slices
+    } else {   // PairNorm here, in fp32 (buf2 is free: rows, then the thread groups' partial sums), then the slices
         float* scratch = reinterpret_cast<float*>(buf2);
         constexpr int lds_ = F + 8;
         pairnorm_tile<BM>(tile_lo, C, tm, a.cl_seg, a.cgseg, a.psum_c_rd, a.cgseg2, a.psum2_c, a.ncv, a.Cs, a.Cs, a.round == 0,
@@ -1332,9 +1326,6 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
             if (c < C) cl = make_float4(4.f * expf(-S[u].x), 4.f * expf(-S[u].y), 4.f * expf(-S[u].z), 4.f * expf(-S[u].w));
             clv[u] = cl;   // (stored to closs4 at the end of the tile: a write-through store here would sit in front of
                            // the weight ring's counted waits until it is acknowledged)
-#ifdef DSAT_EXP_P2_NOSTATE
-            split_st4(buf1, pl_seg, r * ldg + sub * 4, cl);   // EXPERIMENT (wrong results): no state segment in layer 0
-#endif
             const float rw = rwv[u];
             const float4 cm = make_float4(M[u].x * rw, M[u].y * rw, M[u].z * rw, M[u].w * rw);
             split_st4(buf2, pl_seg, r * ldg + sub * 4, cm);
@@ -1355,18 +1346,6 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc0[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
     accp[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef DSAT_EXP_P2_NOSTATE
-    // EXPERIMENT (wrong results; bounds what forming the state segment's products elsewhere would buy):
-    // layer 0 = [messages | loss], eight k-steps, no refill of buf1 in the middle
-    (void)mid;
-    if (full0)
-        split_layer_two<RB, PD>(voff, wb0 + (size_t)KSEG * 192, KSEG, buf2 + xoff, buf1 + xoff, pl_seg, ldg, finish, acc0);
-    else if (part0)
-        split_layer_two<1, PD>(voff, wb0 + (size_t)KSEG * 192, KSEG, buf2 + xoff + prb * 16 * ldg, buf1 + xoff + prb * 16 * ldg,
-                               pl_seg, ldg, finish, accp);
-    else
-        split_layer_two<0, PD>(voff, wb0, KSEG, buf2, buf1, pl_seg, ldg, finish, accp);
-#else
     if (full0)
         split_layer_segments<RB, PD>(voff, wb0, KSEG, buf1 + xoff, buf2 + xoff, pl_seg, ldg, finish, mid, acc0);
     else if (part0)
@@ -1374,7 +1353,6 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
                                     finish, mid, accp);
     else
         split_layer_segments<0, PD>(voff, wb0, KSEG, buf1, buf2, pl_seg, ldg, finish, mid, accp);
-#endif
     DSAT_STAMP(a, 5);
     // ---- layer 1 (one column tile per wave); its prep is layer 0's epilogue: slices of the hidden tile go to buf2
     // (nobody reads the messages any more)

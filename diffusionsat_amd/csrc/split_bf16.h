@@ -231,49 +231,6 @@ __device__ __forceinline__ void split_layer_segments(unsigned voff, const float4
     }
 }
 
-// Two segments of `kseg` k-steps in two buffers, no refill in between (an experiment's form of P2's layer 0, see
-// DSAT_EXP_P2_NOSTATE in kernels_round.hip): steps [0, kseg) read pxA, [kseg, 2 kseg) pxB.
-template <int NRB, int PD, typename Prep>
-__device__ __forceinline__ void split_layer_two(unsigned voff, const float4* __restrict__ wbase, int kseg,
-                                                const unsigned short* pxA, const unsigned short* pxB, int plane, int ld,
-                                                Prep&& prep, sf32x4 (&acc)[NRB > 0 ? NRB : 1]) {
-    if constexpr (NRB == 0) {
-        prep();
-        lds_barrier();
-    } else {
-        const int stot = 2 * kseg, last = stot - 1;
-        SplitSlot ring[PD];
-        split_prime<PD>(ring, voff, wbase, stot);
-        prep();
-        lds_barrier();
-        for (int s = 0; s < stot; s += PD) {
-            const unsigned short* px = s < kseg ? pxA + s * 32 : pxB + (s - kseg) * 32;
-#pragma unroll
-            for (int p = 0; p < PD; ++p) {
-                const unsigned short* q = px + p * 32;
-                split_rotate_prio(s + p);
-                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q), xm = *reinterpret_cast<const bf16x8*>(q + plane),
-                             xl = *reinterpret_cast<const bf16x8*>(q + 2 * plane);
-                asm volatile("s_waitcnt vmcnt(%3)" : "+v"(ring[p].h), "+v"(ring[p].m), "+v"(ring[p].l) : "n"(3 * (PD - 1)) : "memory");
-                split_step<NRB>(ring[p], xh, xm, xl, q, plane, ld, acc);
-                __builtin_amdgcn_sched_barrier(0);
-                const int sn = s + p + PD;
-                const float4* sb = wbase + (size_t)(sn < last ? sn : last) * 192;
-                gload_b128(ring[p].h, voff, sb);
-                gload_b128(ring[p].m, voff, sb + 64);
-                gload_b128(ring[p].l, voff, sb + 128);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0].h), "+v"(ring[0].m), "+v"(ring[0].l) :: "memory");
-#ifndef DSAT_SPLIT_NO_ROTPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#pragma unroll
-        for (int p = 1; p < PD; ++p) asm volatile("" : "+v"(ring[p].h), "+v"(ring[p].m), "+v"(ring[p].l));
-    }
-}
-
 // BARRIER = false: the input is already published (prep() then only has to run somewhere before the k-steps).
 template <int NRB, int PD, bool BARRIER = true, typename Prep>
 __device__ __forceinline__ void split_layer(unsigned voff, const float4* __restrict__ wbase, int stot,
