@@ -25,7 +25,7 @@ for kind in ("medium", "uf20"):
                                  dt=np.float32, trace=("logits",))["trace"]["logits"]
         scale = max(np.abs(ref64[r]).max() for r in range(rounds))
         line = ["%s weights %d  |logits| max %.2f; numpy fp32 oracle: %.2e" % (kind, wseed, scale, max(np.abs(ref32[r] - ref64[r]).max() for r in range(rounds)))]
-        for name, env in (("split", {}), ("split+a2", {"DSAT_P1_A2": "1", "DSAT_P3_BM": "32"}), ("f32mfma", {"DSAT_P2_SPLIT": "0", "DSAT_P3_SPLIT": "0", "DSAT_P1_A2": "0", "DSAT_P1_BSPLIT": "0"}), ("per_layer", {"DSAT_FUSED": "0"})):
+        for name, env in (("split", {}), ("split+a2", {"DSAT_P1_A2": "1", "DSAT_P3_BM": "32"}), ("f32mfma", {"DSAT_P2_SPLIT": "0", "DSAT_P3_SPLIT": "0", "DSAT_P1_A2": "0", "DSAT_P1_BSPLIT": "0", "DSAT_P1_ASPLIT": "0"}), ("per_layer", {"DSAT_FUSED": "0"})):
             os.environ.update(env)
             try:
                 s = rt.Session(rt.Graph(batch), rt.Weights(ws32), max_rounds=rounds)
