@@ -44,6 +44,14 @@ SIGNATURES = {
     "dsat_layout_blob_floats": (_i64, [C.POINTER(Layout)]),
     "dsat_layout_layer_dims": (C.c_int, [C.POINTER(Layout), _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "dsat_graph_create": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _pp]),
+    "dsat_graph_create_coo": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _pp]),
+    "dsat_graph_create_coo_in": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _pp]),
+    "dsat_mlp_create": (C.c_int, [_i32, _vp, _vp, _i64, _pp]),
+    "dsat_mlp_workspace_floats": (_i64, [_vp, _i32]),
+    "dsat_mlp_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "dsat_mlp_destroy": (None, [_vp]),
+    "dsat_pair_norm_workspace_floats": (_i64, [_i32, _i32, _i32]),
+    "dsat_pair_norm": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _f32, _i32, _vp, _vp, _vp]),
     "dsat_graph_destroy": (None, [_vp]),
     "dsat_graph_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)]),
     "dsat_arena_create": (C.c_int, [_i64, _i64, _pp]),

@@ -9,6 +9,7 @@ changed) and the objects are linked into one shared library.
 from __future__ import annotations
 
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -41,14 +42,25 @@ def _deps():
 
 
 def _extra_flags():
-    """Experiment switches: DSAT_CXXFLAGS="-DDSAT_PD1=2 ..." (part of the staleness key)."""
+    """Experiment switches: DSAT_CXXFLAGS="-DDSAT_PD1=2 ..." -- part of the staleness key: the flags a library
+    was built with are recorded next to it (``<lib>.flags``), and a library built with other flags is stale."""
     return os.environ.get("DSAT_CXXFLAGS", "").split()
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB):
+def _built_flags(lib: str):
+    try:
+        with open(lib + ".flags") as f:
+            return f.read().split()
+    except OSError:
+        return []          # libraries from before the sidecar existed were built without extra flags
+
+
+def is_stale(out: str = LIB, extra=None) -> bool:
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(LIB)
+    if _built_flags(out) != (list(extra) if extra is not None else _extra_flags()):
+        return True
+    t = os.path.getmtime(out)
     return any(os.path.getmtime(p) > t for p in _deps() if os.path.exists(p))
 
 
@@ -62,10 +74,10 @@ def _hipcc() -> str:
 def build(force: bool = False, verbose: bool = False, out: str = LIB) -> str:
     """Compile every .hip under csrc/ into one shared library; returns its path."""
     extra = _extra_flags()
-    if not force and not extra and out == LIB and not is_stale():
-        return LIB
+    if not force and not is_stale(out, extra):
+        return out
     hipcc = _hipcc()
-    tag = "" if not extra else "_" + str(abs(hash(" ".join(extra))) % 10**8)
+    tag = "" if not extra else "_" + hashlib.sha1(" ".join(extra).encode()).hexdigest()[:8]
     objdir = OBJDIR + tag
     os.makedirs(objdir, exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in _headers() if os.path.exists(h))
@@ -94,7 +106,21 @@ def build(force: bool = False, verbose: bool = False, out: str = LIB) -> str:
             os.remove(tmp)
         raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, out)
+    with open(out + ".flags", "w") as f:
+        f.write(" ".join(extra))
     return out
+
+
+def source_hash() -> str:
+    """sha1 over csrc/ and include/dsat.h: identifies the kernels a measurement (e.g. the PMC traffic file bench.py
+    reads) was taken on."""
+    h = hashlib.sha1()
+    for p in _deps():
+        if os.path.exists(p):
+            h.update(os.path.basename(p).encode())
+            with open(p, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 if __name__ == "__main__":

@@ -274,6 +274,21 @@ static int graph_create_impl(dsat_arena* arena, hipStream_t st, const int32_t* c
         cseg[g + 1] += cseg[g];
     }
 
+    // Literal order inside a clause: ascending literal row (positive literals by variable, then negative ones by
+    // variable), whatever order the caller listed them in.  The reference's tensor lists a clause's positives before
+    // its negatives too (adj_matrix_lit = concat([adj_indices_pos, adj_indices_neg]), data/SatSpecifics.py:33), and
+    // a fixed order makes the sums of a clause's terms independent of how the formula was written down: the graph
+    // built from the COO tensors (dsat_graph_create_coo, in any entry order) and the one built from the clause
+    // lists are the same graph, bit for bit, and shuffling literals inside clauses changes nothing at all.
+    std::vector<int32_t> canon(clause_lits, clause_lits + E);
+    {
+        auto row_of = [N](int32_t l) { return l > 0 ? (int64_t)l - 1 : (int64_t)N - 1 - (int64_t)l; };
+        for (int c = 0; c < C; ++c)
+            std::stable_sort(canon.begin() + clause_rowptr[c], canon.begin() + clause_rowptr[c + 1],
+                             [&](int32_t a, int32_t b) { return row_of(a) < row_of(b); });
+    }
+    clause_lits = canon.data();
+
     // clause -> literal rows, literal degrees
     std::vector<int32_t> c_lit(E), l_rowptr(2 * (size_t)N + 1, 0);
     int32_t max_len = 0;
@@ -382,6 +397,93 @@ extern "C" int dsat_graph_create_in(dsat_arena* arena, void* stream, const int32
                              N, C, G, out);
 }
 
+// The same graph from the tensors QuerySAT.diffusion_step receives (model/query_sat.py:467-481), exactly as
+// SatSpecifics.create_adj_matrices (data/SatSpecifics.py:21-69) builds them.  Host-side conversion to the clause
+// lists graph_create_impl takes (entries bucketed by clause; graph_create_impl orders a clause's literals itself).
+static int graph_create_coo_impl(dsat_arena* arena, hipStream_t st, const int64_t* adj_indices,
+                                 const float* adj_values, int64_t n_entries, int64_t n_literal_rows,
+                                 int64_t n_clauses, const int64_t* cg_indices, int64_t n_cg,
+                                 const int64_t* vg_indices, int64_t n_vg, int64_t n_graphs, dsat_graph** out) {
+    DSAT_REQUIRE(out != nullptr, DSAT_E_INVALID, "dsat_graph_create_coo: null out");
+    *out = nullptr;
+    DSAT_REQUIRE(n_entries >= 0 && n_clauses >= 0 && n_graphs > 0 && n_literal_rows > 0, DSAT_E_INVALID,
+                 "dsat_graph_create_coo: need n_entries>=0, n_clauses>=0, n_graphs>0, n_literal_rows>0");
+    DSAT_REQUIRE(n_literal_rows % 2 == 0, DSAT_E_INVALID,
+                 "dsat_graph_create_coo: adj_matrix must have 2*n_vars rows (positive literals, then negative ones)");
+    DSAT_REQUIRE(n_literal_rows < ((int64_t)1 << 31) && n_clauses < ((int64_t)1 << 31) && n_graphs < ((int64_t)1 << 31),
+                 DSAT_E_INVALID, "dsat_graph_create_coo: graph too large for int32 indexing");
+    const int64_t N = n_literal_rows / 2, C = n_clauses, G = n_graphs;
+    DSAT_REQUIRE((n_entries == 0 || adj_indices) && (C == 0 || cg_indices) && vg_indices, DSAT_E_INVALID,
+                 "dsat_graph_create_coo: null index array");
+    DSAT_REQUIRE(n_vg == N, DSAT_E_INVALID,
+                 "dsat_graph_create_coo: variables_graph must hold one entry per variable (data/SatSpecifics.py:52-57)");
+    DSAT_REQUIRE(n_cg == C, DSAT_E_INVALID,
+                 "dsat_graph_create_coo: clauses_graph must hold one entry per clause (data/SatSpecifics.py:45-50)");
+    // membership matrices: one (graph, index) pair per column, in any order
+    std::vector<int32_t> vgid((size_t)N, -1), cgid((size_t)C, -1);
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t g = vg_indices[2 * i], v = vg_indices[2 * i + 1];
+        DSAT_REQUIRE(g >= 0 && g < G && v >= 0 && v < N, DSAT_E_INVALID, "dsat_graph_create_coo: variables_graph index out of range");
+        DSAT_REQUIRE(vgid[v] < 0, DSAT_E_INVALID, "dsat_graph_create_coo: a variable belongs to two graphs");
+        vgid[v] = (int32_t)g;
+    }
+    for (int64_t i = 0; i < C; ++i) {
+        const int64_t g = cg_indices[2 * i], c = cg_indices[2 * i + 1];
+        DSAT_REQUIRE(g >= 0 && g < G && c >= 0 && c < C, DSAT_E_INVALID, "dsat_graph_create_coo: clauses_graph index out of range");
+        DSAT_REQUIRE(cgid[c] < 0, DSAT_E_INVALID, "dsat_graph_create_coo: a clause belongs to two graphs");
+        cgid[c] = (int32_t)g;
+    }
+    // adjacency: value k (a whole number >= 1; the reference writes 1.0) = k parallel entries
+    std::vector<int32_t> rowptr((size_t)C + 1, 0);
+    std::vector<int32_t> mult((size_t)n_entries, 1);
+    int64_t E = 0;
+    for (int64_t e = 0; e < n_entries; ++e) {
+        const int64_t l = adj_indices[2 * e], c = adj_indices[2 * e + 1];
+        DSAT_REQUIRE(l >= 0 && l < n_literal_rows && c >= 0 && c < C, DSAT_E_INVALID,
+                     "dsat_graph_create_coo: adj_matrix index out of range");
+        if (adj_values != nullptr) {
+            const float v = adj_values[e];
+            DSAT_REQUIRE(v >= 1.f && v <= 1024.f && v == std::floor(v), DSAT_E_UNSUPPORTED,
+                         "dsat_graph_create_coo: adj_matrix values must be whole multiplicities >= 1 (the reference "
+                         "writes 1.0, data/SatSpecifics.py:76-80)");
+            mult[e] = (int32_t)v;
+        }
+        rowptr[c + 1] += mult[e];
+        E += mult[e];
+        DSAT_REQUIRE(E < ((int64_t)1 << 31) - 1, DSAT_E_INVALID, "dsat_graph_create_coo: graph too large for int32 indexing");
+    }
+    for (int64_t c = 0; c < C; ++c) rowptr[c + 1] += rowptr[c];
+    std::vector<int32_t> lits((size_t)E), cursor(rowptr.begin(), rowptr.end() - 1);
+    for (int64_t e = 0; e < n_entries; ++e) {
+        const int64_t l = adj_indices[2 * e], c = adj_indices[2 * e + 1];
+        const int32_t lit = l < N ? (int32_t)(l + 1) : -(int32_t)(l - N + 1);   // data/SatSpecifics.py:25-35
+        for (int k = 0; k < mult[e]; ++k) lits[cursor[c]++] = lit;
+    }
+    return graph_create_impl(arena, st, rowptr.data(), lits.data(), vgid.data(), cgid.data(), (int32_t)N, (int32_t)C,
+                             (int32_t)G, out);
+}
+
+extern "C" int dsat_graph_create_coo(const int64_t* adj_indices, const float* adj_values, int64_t n_entries,
+                                      int64_t n_literal_rows, int64_t n_clauses,
+                                      const int64_t* clauses_graph_indices, int64_t n_clauses_graph_entries,
+                                      const int64_t* variables_graph_indices, int64_t n_variables_graph_entries,
+                                      int64_t n_graphs, dsat_graph** out) {
+    return graph_create_coo_impl(nullptr, nullptr, adj_indices, adj_values, n_entries, n_literal_rows, n_clauses,
+                                 clauses_graph_indices, n_clauses_graph_entries, variables_graph_indices,
+                                 n_variables_graph_entries, n_graphs, out);
+}
+
+extern "C" int dsat_graph_create_coo_in(dsat_arena* arena, void* stream, const int64_t* adj_indices,
+                                         const float* adj_values, int64_t n_entries, int64_t n_literal_rows,
+                                         int64_t n_clauses, const int64_t* clauses_graph_indices,
+                                         int64_t n_clauses_graph_entries, const int64_t* variables_graph_indices,
+                                         int64_t n_variables_graph_entries, int64_t n_graphs, dsat_graph** out) {
+    DSAT_REQUIRE(arena != nullptr, DSAT_E_INVALID, "dsat_graph_create_coo_in: null arena");
+    return graph_create_coo_impl(arena, (hipStream_t)stream, adj_indices, adj_values, n_entries, n_literal_rows,
+                                 n_clauses, clauses_graph_indices, n_clauses_graph_entries, variables_graph_indices,
+                                 n_variables_graph_entries, n_graphs, out);
+}
+
 extern "C" void dsat_graph_destroy(dsat_graph* g) {
     if (!g) return;
     if (g->arena != nullptr) {
@@ -434,6 +536,11 @@ extern "C" int dsat_arena_usage(const dsat_arena* a, int64_t* device_used, int64
 
 extern "C" void dsat_arena_destroy(dsat_arena* a) {
     if (!a) return;
+    if (a->live != 0) {   // graphs / sessions carved from it still point into it (and count themselves out at destroy)
+        set_error("dsat_arena_destroy: " + std::to_string(a->live) + " object(s) created in the arena are still alive; "
+                  "destroy them first (the arena was NOT freed)");
+        return;
+    }
     if (a->dev) (void)hipFree(a->dev);
     if (a->pin) (void)hipHostFree(a->pin);
     delete a;
@@ -1041,7 +1148,7 @@ static bool plan_round(dsat_session* s) {
         // Twice the rows per CU-cycle, but no shorter for a batch whose 16-row tiles all have a CU of their own
         // (config 2: 194 + 49 workgroups; and the bf16 pipe's power costs the rest of the round 3 % of its clock):
         // by default only for batches of more than one wave of workgroups, or when the caller asks for throughput
-        const bool large = (g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + s->pair_blocks > 256;
+        const bool large = (g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + s->pair_blocks > s->n_cus;
         s->p1_a2 = s->p1_a2_ok && (s->p1_a2_env == 1 || (s->p1_a2_env == -1 && large));
         // 16-row tiles as split products: the same shapes; 57 k cycles per tile against 69 k on the fp32 MFMA
         // (tools/lit16w_probe.hip).  DSAT_P1_ASPLIT=0 keeps the fp32-MFMA chain.
@@ -1195,6 +1302,12 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
     { int rc = require_device(g->device, "dsat_session_create"); if (rc != DSAT_OK) return rc; }
     std::unique_ptr<dsat_session> s(new dsat_session());
     s->device = g->device;
+    {   // launch planning counts CUs (one 1024-thread workgroup per CU): the device's own number, not a literal 256
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device) == hipSuccess && cus > 0)
+            s->n_cus = cus;
+        if (const char* e = getenv("DSAT_N_CUS")) { const int v = atoi(e); if (v >= 8) s->n_cus = v; }   // planning experiments
+    }
     s->g = g; s->w = w; s->max_rounds = max_rounds;
     s->no_cn = getenv("DSAT_NO_CN") != nullptr;
     memset(&s->tap, 0, sizeof(s->tap));
@@ -1221,7 +1334,7 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             const int ldx = up[0].ksteps() * 32 + 16;
             const bool fits = 3 * 32 * ldx * 2 + 3 * 32 * ldh * 2 + ROUND_NWAVES * 64 * 4 <= ROUND_LDS_FLOATS * 4 && ldh <= ldx &&
                               32 * (F + 8) * 4 <= 3 * 32 * ldh * 2;
-            const bool large = (g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR > 256;
+            const bool large = (g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR > s->n_cus;
             const int want = e32 != nullptr ? atoi(e32) : (large ? 32 : 16);
             s->p3_bm = (shapes && fits && want == 32) ? 32 : ROUND_BM_VAR;
         }
@@ -1519,6 +1632,8 @@ extern "C" int dsat_session_set_tap(dsat_session* s, const dsat_tap* tap) {
 extern "C" int dsat_session_set_retire(dsat_session* s, int32_t enable) {
     DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_retire: null session");
     if (!enable) { s->retire = 0; return DSAT_OK; }
+    DSAT_REQUIRE(!s->profile, DSAT_E_STATE,
+                 "dsat_session_set_retire: profiling is on (dsat_session_set_profile); it times the non-retiring sequence");
     DSAT_REQUIRE(s->g->identical_copies, DSAT_E_UNSUPPORTED,
                  "dsat_session_set_retire: the batch is not a set of identical copies of one formula");
     DSAT_REQUIRE(s->use_fused, DSAT_E_UNSUPPORTED, "dsat_session_set_retire: needs the fused round kernels");
@@ -1531,6 +1646,9 @@ extern "C" int dsat_session_set_retire(dsat_session* s, int32_t enable) {
 
 extern "C" int dsat_session_set_profile(dsat_session* s, int32_t enable) {
     DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_profile: null session");
+    DSAT_REQUIRE(!(enable && s->retire), DSAT_E_STATE,
+                 "dsat_session_set_profile: the session retires solved copies (dsat_session_set_retire); the profiling "
+                 "pass times the non-retiring launch sequence, so the two cannot be on together");
     s->profile = enable ? 1 : 0;
     return DSAT_OK;
 }
@@ -1763,19 +1881,19 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
     }
 }
 
-// How many 64-row groups P1's role B should cover.  One workgroup per CU, 256 CUs, workgroups start in block
-// order: with a single wave of workgroups (vtiles + groups <= 256) everything is co-resident and role B takes
+// How many 64-row groups P1's role B should cover.  One workgroup per CU, n_cus CUs, workgroups start in block
+// order: with a single wave of workgroups (vtiles + groups <= n_cus) everything is co-resident and role B takes
 // all groups.  On larger grids a few workgroups too many cost a whole extra tile time at the end (625 + 157
 // workgroups = 3.05 waves), so the candidates are compared by a list-scheduling estimate with the measured
 // relative durations (profiles/r02_stamps_*: A tile without the pair 74, with it 95, role-B workgroup 72).
-static void plan_pair_blocks(int n_active, int* first, int* blocks) {
+static void plan_pair_blocks(int n_cus, int n_active, int* first, int* blocks) {
     const int vtiles = (n_active + ROUND_BM_VAR - 1) / ROUND_BM_VAR, groups = (n_active + 63) / 64;
     *first = 0;
     *blocks = groups;
-    if (vtiles + groups <= 256) return;
+    if (vtiles + groups <= n_cus) return;
     auto makespan = [&](int nb) {
         const int f = groups - nb;                    // rows below 64*f: pair in the A tile
-        std::vector<double> cu(256, 0.0);             // finish times; the next block goes to the earliest CU
+        std::vector<double> cu(n_cus, 0.0);           // finish times; the next block goes to the earliest CU
         std::make_heap(cu.begin(), cu.end(), std::greater<double>());
         auto put = [&](double d) {
             std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
@@ -1805,7 +1923,7 @@ static int role_d_blocks(const dsat_session* s, int actN, int actC, bool sel_on,
     *dsel = 0;
     if (!s->p3_part || s->prefer_tp || s->p2_rb != 4) return 0;
     const int p2_blocks = (actC + 63) / 64 + (sel_on ? (sel_lead > 0 ? sel_lead : n_sel) : 0);
-    const int nd = (actN + 63) / 64, free_cus = 256 - p2_blocks;
+    const int nd = (actN + 63) / 64, free_cus = s->n_cus - p2_blocks;
     const int sel_workers = sel_on && sel_lead == 0 ? n_sel : 0;
     const int extra_blocks = std::min(std::max(nd - sel_workers, 1), std::max(free_cus, 0));
     if (free_cus < 8 || nd > 3 * extra_blocks + sel_workers) return 0;
@@ -1853,12 +1971,12 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         if (s->p1_a2) {                       // 32-row A tiles: role B covers every group, in the tail launch too
             a1.pair_blocks = (actN + 63) / 64;
         } else if (!a1.tail && s->pair_blocks != 0) {
-            if (r == 0 || pb_blocks < 0) plan_pair_blocks(actN, &pb_first, &pb_blocks);
+            if (r == 0 || pb_blocks < 0) plan_pair_blocks(s->n_cus, actN, &pb_first, &pb_blocks);
             a1.pair_blocks = pb_blocks;
             a1.pair_first = pb_first;
         }
         a1.a1_split = s->p1_a1s && !s->p1_a2 && !a1.tail && a1.pair_first == 0 && a1.pair_blocks == (actN + 63) / 64;
-        const int free_cus = 256 - (s->p1_a2 ? a1.a2_tiles : vtiles) - a1.pair_blocks;
+        const int free_cus = s->n_cus - (s->p1_a2 ? a1.a2_tiles : vtiles) - a1.pair_blocks;
         const int cn = (r > 0 && r < rounds && actC > 0 && free_cus >= 8 && !s->no_cn) ? free_cus : 0;
         a1.cn_blocks = cn;
         float* vbuf[2] = {s->V, s->Vlog};   // carried state, double-buffered by round (Vlog is free on this path)
@@ -2142,7 +2260,7 @@ static int sample_impl(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_
     DSAT_REQUIRE(assignment_out != nullptr, DSAT_E_INVALID, "dsat_sample: assignment_out is required");
     DSAT_REQUIRE(!s->tap_on, DSAT_E_STATE, "dsat_sample: a debug tap is set (taps belong to dsat_diffusion_step)");
     { int rc = require_device(s->device, "dsat_sample"); if (rc != DSAT_OK) return rc; }
-    if (s->retire && !s->profile)
+    if (s->retire)
         return sample_retire_impl(s, n_steps, rounds, seed, early_exit, uniform, normal, labels, assignment_out,
                                   solved_out, prediction_steps_out, solved_fraction_out, (hipStream_t)stream,
                                   self_conditioning);
@@ -2454,7 +2572,7 @@ extern "C" int dsat_session_set_throughput(dsat_session* s, int32_t enable) {
     DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_throughput: null session");
     s->prefer_tp = enable != 0;   // (role D of P2 spends CU-cycles to shorten one batch's P3: off when batches overlap)
     if (s->p1_a2_env == -1) {
-        const bool large = (s->g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + s->pair_blocks > 256;
+        const bool large = (s->g->N + ROUND_BM_VAR - 1) / ROUND_BM_VAR + s->pair_blocks > s->n_cus;
         s->p1_a2 = s->p1_a2_ok && (enable != 0 || large);
     }
     return DSAT_OK;

@@ -12,18 +12,31 @@ themselves (``tests/golden/dimacs_golden.json``).
 """
 from __future__ import annotations
 
+import itertools
 from typing import Iterable, List, Sequence
 
 
 class DimacsFile:
-    """CNF container with the reference's parsing rules (utils/DimacsFile.py:49-85).
+    """CNF container that reads DIMACS text the way the reference's class does (utils/DimacsFile.py:39-85).
 
-    Parsing rules kept: a line containing ``p cnf`` sets ``n_vars`` from the first
-    number after it; lines starting with a letter are comments except ``v`` lines,
-    which assign variables; lines starting with ``--`` are skipped; any other line
-    is a clause terminated by the first ``0``; ``n_vars`` grows to cover every
-    literal seen (``add_clauses``, :101-107).
+    The line rules below are written down from observed behaviour: ``tests/golden/dimacs_golden.json`` holds
+    what the reference class itself returns -- or which error it raises -- for ordinary files and for every
+    corner named here (``tests/golden/make_dimacs_golden.py``).
+
+    * blank lines are skipped; surrounding blanks, tabs and ``\r`` never matter;
+    * a line that contains ``p cnf`` is the header.  The variable count is read at a fixed place, right
+      behind the line's first five characters, and ends at the next space -- so a header that does not
+      start its line, or a comment that mentions ``p cnf``, is a ``ValueError``, and a header without a
+      clause count loses its last digit (``p cnf 12`` reads 1);
+    * other lines that start with a letter are comments, except ``v`` lines: every non-zero number on
+      them assigns a variable (``b_values``), the first may be glued to the ``v``;
+    * lines that start with ``--`` are skipped;
+    * anything else is a clause: the numbers up to the first ``0`` (what follows it is not looked at; a
+      missing ``0`` is fine, a lone ``0`` is the empty clause).  SATLIB's ``%`` trailer is a ``ValueError``;
+    * ``n_vars`` grows to cover every literal seen.
     """
+
+    HEADER = "p cnf"
 
     def __init__(self, filename: str = "file.cnf", n_vars: int = 0, clauses=None):
         clauses = [list(map(int, c)) for c in clauses] if clauses is not None else []
@@ -45,37 +58,32 @@ class DimacsFile:
         self.load_from_lines(text.split("\n"))
         return self
 
+    @classmethod
+    def _kind(cls, line: str) -> str:
+        if not line:
+            return "blank"
+        if cls.HEADER in line:
+            return "header"
+        if line[0].isalpha():
+            return "values" if line[0] == "v" else "comment"
+        return "comment" if line[:2] == "--" else "clause"
+
+    @classmethod
+    def _header_count(cls, line: str) -> int:
+        field = line[len(cls.HEADER):].lstrip()
+        return int(field[:field.find(" ")])          # no further space: find() is -1 and the last character goes
+
     def load_from_lines(self, lines: Iterable[str]):
-        self.n_vars = 0
-        self.i_clauses = []
-        for line in lines:
-            line = line.strip()
-            if not line:
-                continue
-            i = line.find("p cnf")
-            if i >= 0:
-                rest = line[len("p cnf"):].strip()
-                j = rest.find(" ")
-                self.n_vars = int(rest[:j])
-                continue
-            if line[0].isalpha():
-                if line[0] == "v":
-                    for s in line[1:].strip().split():
-                        v = int(s)
-                        if v > 0:
-                            self.b_values[v] = True
-                        if v < 0:
-                            self.b_values[-v] = False
-                continue
-            if line.startswith("--"):
-                continue
-            clause = []
-            for s in line.split():
-                v = int(s)
-                if v == 0:
-                    break
-                clause.append(v)
-            self.add_clause(clause)
+        self.n_vars, self.i_clauses = 0, []
+        for line in map(str.strip, lines):
+            kind = self._kind(line)
+            if kind == "header":
+                self.n_vars = self._header_count(line)
+            elif kind == "values":
+                self.b_values.update((abs(v), v > 0) for v in map(int, line[1:].split()) if v)
+            elif kind == "clause":
+                # lazily: nothing behind the terminating zero is parsed
+                self.add_clause(list(itertools.takewhile(bool, map(int, line.split()))))
 
     # -- accessors -----------------------------------------------------------
     def number_of_vars(self) -> int:

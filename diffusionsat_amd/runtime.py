@@ -78,8 +78,10 @@ class Arena:
                 "pinned_needed": v[3].value}
 
     def close(self):
+        """Frees the arena; raises while graphs / sessions created in it are still open (their arrays live here)."""
         if getattr(self, "handle", None):
             with torch.cuda.device(self.device):
+                _lib.check(_lib.load().dsat_arena_reset(self.handle))      # DSAT_E_STATE: objects still alive
                 _lib.load().dsat_arena_destroy(self.handle)
             self.handle = None
 
@@ -114,6 +116,40 @@ class Graph:
         self.handle = h
         self.n_vars, self.n_clauses, self.n_graphs, self.n_edges = (
             batch.n_vars, batch.n_clauses, batch.n_graphs, batch.n_edges)
+
+    @classmethod
+    def from_coo(cls, adj_matrix, clauses_graph, variables_graph, device=None, arena: Optional[Arena] = None):
+        """The device graph from the three sparse tensors ``QuerySAT.diffusion_step`` receives in the
+        reference (model/query_sat.py:467-481; built by data/SatSpecifics.py:21-69), through
+        ``dsat_graph_create_coo``.  Anything ``sparse.as_coo`` understands is accepted."""
+        from . import sparse
+        lib = _lib.load()
+        adj, cg, vg = sparse.as_coo(adj_matrix), sparse.as_coo(clauses_graph), sparse.as_coo(variables_graph)
+        if cg.dense_shape[0] != vg.dense_shape[0]:
+            raise ValueError("clauses_graph has %d graphs, variables_graph %d" % (cg.dense_shape[0], vg.dense_shape[0]))
+        if adj.dense_shape != (2 * vg.dense_shape[1], cg.dense_shape[1]):
+            raise ValueError("adj_matrix is %s; the memberships describe %d variables and %d clauses"
+                             % (adj.dense_shape, vg.dense_shape[1], cg.dense_shape[1]))
+        self = cls.__new__(cls)
+        self.arena = arena
+        self.device = arena.device if (arena is not None and device is None) else _device(device)
+        values = None if np.all(adj.values == 1.0) else adj.values
+        self._keep = [adj.indices, values, cg.indices, vg.indices]
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if (a is not None and a.size) else None
+        h = C.c_void_p()
+        args = (p(adj.indices), p(values), adj.indices.shape[0], adj.dense_shape[0], adj.dense_shape[1],
+                p(cg.indices), cg.indices.shape[0], p(vg.indices), vg.indices.shape[0], cg.dense_shape[0], C.byref(h))
+        with torch.cuda.device(self.device):
+            if arena is None:
+                _lib.check(lib.dsat_graph_create_coo(*args))
+            else:
+                _lib.check(lib.dsat_graph_create_coo_in(arena.handle, _stream(self.device), *args))
+        self.handle = h
+        nv, nc, ne, ng = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32()
+        _lib.check(lib.dsat_graph_info(h, C.byref(nv), C.byref(nc), C.byref(ne), C.byref(ng)))
+        self.n_vars, self.n_clauses, self.n_graphs, self.n_edges = nv.value, nc.value, ng.value, ne.value
+        self.batch = None
+        return self
 
     def close(self):
         if getattr(self, "handle", None):

@@ -246,6 +246,19 @@ def load_queriesat_weights(model_path: str, layout=None, base: Optional[WeightSe
     report["unused"] = sorted(k for k in tensors if k not in used)
     last_restore_report.clear()
     last_restore_report.update(report)
+    # expect_partial() tolerates gaps, but a file that fills none of an MLP's variables is not a QuerySAT
+    # checkpoint under these key names (they are derived from the source, SURVEY.md §5: unverified against a
+    # TensorFlow-written file): report it instead of sampling with fresh weights that claim to be restored
+    wholly_missing = [name for name, dims in layer_dims(layout)
+                      if not any(k.startswith("model/%s/" % name) for k in report["restored"])]
+    if wholly_missing:
+        raise KeyError("checkpoint %s holds no variables of %s under model/<mlp>/dense_layers/<i>/{kernel,bias} "
+                       "(%d tensors in the file; first keys: %s)"
+                       % (prefix, ", ".join(wholly_missing), len(tensors), sorted(tensors)[:4]))
+    if report["missing"]:
+        import warnings
+        warnings.warn("checkpoint %s: %d model variable(s) keep their initial values: %s"
+                      % (prefix, len(report["missing"]), ", ".join(report["missing"])))
     return ws
 
 

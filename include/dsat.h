@@ -82,6 +82,8 @@ int dsat_layout_layer_dims(const dsat_layout* layout, int32_t mlp, int32_t layer
  *   clause_lits   [E]    host, int32, signed DIMACS literals in BATCH numbering:
  *                        +v / -v with 1 <= v <= N (duplicates allowed; they add up,
  *                        as duplicate COO entries do in tf.sparse.sparse_dense_matmul)
+ *                        (the order of the literals inside a clause does not matter: the graph keeps them by
+ *                        ascending literal row, so a clause's sums have one fixed order)
  *   var_graph_id  [N]    host, int32 in [0,G), non-decreasing, every graph non-empty
  *   clause_graph_id [C]  host, int32 in [0,G), non-decreasing
  * Every literal of a clause must belong to the clause's graph (block-diagonal batch).
@@ -89,6 +91,26 @@ int dsat_layout_layer_dims(const dsat_layout* layout, int32_t mlp, int32_t layer
 int dsat_graph_create(const int32_t* clause_rowptr, const int32_t* clause_lits,
                       const int32_t* var_graph_id, const int32_t* clause_graph_id,
                       int32_t n_vars, int32_t n_clauses, int32_t n_graphs, dsat_graph** out);
+/* The same graph from the three sparse tensors QuerySAT.diffusion_step is called with
+ * (model/query_sat.py:467-481: adj_matrix, clauses_graph, variables_graph), exactly as
+ * SatSpecifics.create_adj_matrices builds them (data/SatSpecifics.py:21-69), so that the reference's own
+ * step_data can be passed through unchanged.  All arrays host memory, read during the call only.
+ *   adj_indices [n_entries][2] int64   SparseTensor.indices of adj_matrix: (literal row, clause); rows
+ *                                      0..N-1 are the positive literals, N..2N-1 the negative ones (:25-35);
+ *                                      any order, duplicates kept (they add up)
+ *   adj_values  [n_entries] or NULL    SparseTensor.values; the reference writes 1.0 (:76-80); whole numbers
+ *                                      k >= 1 count as k parallel entries, anything else DSAT_E_UNSUPPORTED
+ *   n_literal_rows, n_clauses          SparseTensor.dense_shape of adj_matrix = [2N, C]
+ *   clauses_graph_indices [C][2]       indices of clauses_graph [G x C]: (graph, clause), one per clause (:45-50)
+ *   variables_graph_indices [N][2]     indices of variables_graph [G x N]: (graph, variable) (:52-57)
+ * Both routes order a clause's literals the same way (ascending literal row), so the entry order of the
+ * tensor does not matter and this graph is, bit for bit, the one dsat_graph_create builds from the same
+ * clauses.  Graphs must be contiguous index ranges, as the reference's batches are; otherwise DSAT_E_INVALID. */
+int dsat_graph_create_coo(const int64_t* adj_indices, const float* adj_values, int64_t n_entries,
+                          int64_t n_literal_rows, int64_t n_clauses,
+                          const int64_t* clauses_graph_indices, int64_t n_clauses_graph_entries,
+                          const int64_t* variables_graph_indices, int64_t n_variables_graph_entries,
+                          int64_t n_graphs, dsat_graph** out);
 void dsat_graph_destroy(dsat_graph* g);
 int dsat_graph_info(const dsat_graph* g, int32_t* n_vars, int32_t* n_clauses,
                     int64_t* n_edges, int32_t* n_graphs);
@@ -129,6 +151,8 @@ int dsat_arena_create(int64_t device_bytes, int64_t pinned_bytes, dsat_arena** o
 int dsat_arena_reset(dsat_arena* a);
 int dsat_arena_usage(const dsat_arena* a, int64_t* device_used, int64_t* pinned_used,
                      int64_t* device_needed, int64_t* pinned_needed);
+/* Frees the arena.  While objects created in it are alive this does nothing but set dsat_last_error():
+ * their device arrays live in the arena and their destroy calls count themselves out of it. */
 void dsat_arena_destroy(dsat_arena* a);
 int dsat_graph_create_in(dsat_arena* arena, void* stream, const int32_t* clause_rowptr,
                          const int32_t* clause_lits, const int32_t* var_graph_id,
@@ -136,6 +160,11 @@ int dsat_graph_create_in(dsat_arena* arena, void* stream, const int32_t* clause_
                          int32_t n_graphs, dsat_graph** out);
 int dsat_session_create_in(dsat_arena* arena, void* stream, const dsat_graph* g, const dsat_weights* w,
                            int32_t max_rounds, dsat_session** out);
+int dsat_graph_create_coo_in(dsat_arena* arena, void* stream, const int64_t* adj_indices,
+                             const float* adj_values, int64_t n_entries, int64_t n_literal_rows,
+                             int64_t n_clauses, const int64_t* clauses_graph_indices,
+                             int64_t n_clauses_graph_entries, const int64_t* variables_graph_indices,
+                             int64_t n_variables_graph_entries, int64_t n_graphs, dsat_graph** out);
 
 /* One denoising step = QuerySAT.diffusion_step (model/query_sat.py:467-481) ->
  * call (:133-184) -> loop (:186-373) at inference, for `rounds` message-passing
@@ -201,7 +230,9 @@ int dsat_sample(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_t seed,
  * its outputs are those of the non-retiring run, except that the batch-global early exit
  * (is_batch_sat, model/query_sat.py:330-338) then refers to the copies still in the batch.  Costs one
  * host synchronisation per denoising step.  DSAT_E_UNSUPPORTED when the graphs of the batch are not
- * identical copies, or the formula is large enough to have its select / PairNorm work split. */
+ * identical copies, or the formula is large enough to have its select / PairNorm work split; DSAT_E_STATE
+ * while profiling is on (dsat_session_set_profile times the non-retiring launch sequence; the two exclude
+ * each other, whichever is asked for second is refused). */
 int dsat_session_set_retire(dsat_session* s, int32_t enable);
 
 /* diffusion() with the reference's `self_supervised` switch on
@@ -262,6 +293,39 @@ int dsat_op_pack_assignment(dsat_session* s, const uint8_t* assignment, uint8_t*
  * uniform [N]) for a given (seed, step_index); any output may be NULL. */
 int dsat_op_rng(dsat_session* s, uint64_t seed, uint32_t step_index, int32_t rounds,
                 float* normal_out, int32_t* labels_out, float* uniform_out, void* stream);
+
+/* ---- layers (free-standing objects with the reference's own argument lists) -----------------------
+ * MLP(layer_count, hidden_nmap, out_nmap, activation=tf.nn.leaky_relu)(inputs) of model/mlp.py:13-50 in the
+ * configuration QuerySAT builds its five MLPs in (do_layer_norm=False, dropout_rate=0, out_activation=None;
+ * model/query_sat.py:117-122): layer_count-1 Dense(hidden) with leaky_relu(0.2), then a linear Dense(out).  Any
+ * widths; not bound to a session or to the five roles of dsat_layout.
+ *   dims  host int32 [n_layers+1]: input width, then every layer's output width
+ *   blob  host or dev: per layer kernel[in,out] row-major (Keras Dense), then bias[out]
+ * dsat_mlp_forward: x dev [rows, dims[0]] -> y dev [rows, dims[n_layers]]; workspace dev, at least
+ * dsat_mlp_workspace_floats(m, rows) floats, the caller's (a torch tensor).  Stream-ordered. */
+typedef struct dsat_mlp dsat_mlp;
+int dsat_mlp_create(int32_t n_layers, const int32_t* dims, const float* blob, int64_t n_floats,
+                    dsat_mlp** out);
+int64_t dsat_mlp_workspace_floats(const dsat_mlp* m, int32_t rows);
+int dsat_mlp_forward(const dsat_mlp* m, const float* x, int32_t rows, float* y, float* workspace,
+                     void* stream);
+void dsat_mlp_destroy(dsat_mlp* m);
+/* PairNorm(epsilon=1e-6, subtract_mean=False)(inputs, graph=None) of layers/normalization.py:31-71 on
+ * x dev [rows, width], any width:
+ *   subtract_mean != 0: inputs -= gather(graph @ inputs, graph.indices[:,0]) (:52-54), or the column mean over
+ *                       all rows when there is no graph (n_graphs = 0, :55-57); then, in both cases,
+ *   y = inputs * rsqrt(mean(inputs^2 over the features) + epsilon)              (:69-71)
+ *   seg        host int32 [n_graphs+1]: graph g owns rows [seg[g], seg[g+1]) -- graph.indices[:,0] of the
+ *              reference's membership matrices is non-decreasing (data/SatSpecifics.py:40-57)
+ *   row_weight dev [rows] or NULL: graph.values per row (QuerySAT passes 1/|graph|, model/query_sat.py:206-211);
+ *              NULL = 1/|graph|
+ *   workspace  dev, dsat_pair_norm_workspace_floats(rows, width, n_graphs) floats; may be NULL when
+ *              subtract_mean = 0
+ * Stream-ordered, except that seg is copied to the device before the call returns (one stream wait). */
+int64_t dsat_pair_norm_workspace_floats(int32_t rows, int32_t width, int32_t n_graphs);
+int dsat_pair_norm(const float* x, int32_t rows, int32_t width, const int32_t* seg, int32_t n_graphs,
+                   const float* row_weight, float epsilon, int32_t subtract_mean, float* y,
+                   float* workspace, void* stream);
 
 /* Average device time in microseconds of the kernels of the last
  * dsat_diffusion_step/dsat_sample call when profiling was enabled with

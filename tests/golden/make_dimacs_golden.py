@@ -38,6 +38,18 @@ def main():
         "c sol 1 0 1\np cnf 3 2\n1 2 0\n-- awkward\n3 0\nv 1 -2 3 0\n",
         "p cnf 2 1\n 1   2   0   \n\n-7 0\n",
         "p cnf 4 2\n1 2 0 3 4\n-1 -2 0\n",
+        # corner cases of the line rules (round 3: the parser was re-derived from these behaviours)
+        "p cnf 12\n1 -2 0\n",                                  # header without a clause count
+        "  c indented comment\n\tp cnf 6 1\t\n\t1\t-6\t0\n",   # tabs and leading blanks
+        "junk before p cnf 9 1 trailing words\n3 -4 0\n",       # "p cnf" not at the start of its line
+        "p cnf 3 1\nv1 -2 0 3\nV 3\nx 5\n1 2 3 0\n",              # v-lines (glued first number, zero inside), other letters
+        "p cnf 3 1\nvalues 2\n1 2 3 0\n",                        # a word that starts with v
+        "p cnf 2 3\n0\n1 0\n--2 0\n-- 1 2\n2\n",                  # empty clause, "--" lines, no terminating zero
+        "p cnf 2 1\n- 1 0\n",                                    # a lone minus sign
+        "c only comments\nc p cnf in a comment 5 5\n",            # a comment line that contains "p cnf"
+        "c p cnf 5 5\n1 0\n",                                     # ... with numbers right behind it
+        "p cnf 7 1 \n%\n0\n",                                    # SATLIB trailer lines
+        "p cnf 3 2\r\n1 -3 0\r\n2 0\r\n",                       # CRLF
     ]
     for _ in range(6):
         n = rnd.randint(3, 12)
@@ -50,7 +62,11 @@ def main():
         texts.append("\n".join(lines))
     for t in texts:
         df = DimacsFile()
-        df.load_from_string(t)
+        try:
+            df.load_from_string(t)
+        except Exception as e:                      # a text the reference refuses: the class of the error is the fixture
+            out["parse"].append({"text": t, "raises": type(e).__name__})
+            continue
         out["parse"].append({"text": t, "n_vars": df.number_of_vars(), "clauses": df.clauses(),
                              "b_values": {str(k): v for k, v in df.b_values.items()},
                              "str": str(df)})

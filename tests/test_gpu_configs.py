@@ -285,6 +285,65 @@ def test_early_retirement_matches_the_full_batch(rt):
         mixed.set_retire(True)
 
 
+def test_early_retirement_with_copy_boundaries_inside_tiles(rt):
+    """Copies of a 5-variable / 7-clause formula: 3.2 copies per 16-row variable tile, 9.1 per clause tile, 37
+    copies (no multiple of 16), so the active prefix ends inside a tile after almost every retirement.  A copy's
+    PairNorm sums then depend on which tile boundaries cut it, so the logits are equal to fp32 rounding rather than
+    bitwise: solved flags and assignments agree with the non-retiring run on (nearly) every copy, every flag is
+    re-checked on the host, the run is deterministic, and profiling and retirement exclude each other."""
+    from diffusionsat_amd import _lib
+    from diffusionsat_amd.batch import make_batch
+    n, clauses = 5, [[1, -2, 3], [-1, 4], [2, 5, -3], [-4, -5, 1], [3, 4, 5], [-2, -3], [1, 2, -5]]
+    G, T, R = 37, 8, 4
+    batch = make_batch([(n, clauses)] * G)
+    g, w = rt.Graph(batch), rt.Weights(oracle_weights(4))
+    full = rt.Session(g, w, max_rounds=R)
+    ret = rt.Session(g, w, max_rounds=R)
+    ret.set_retire(True)
+    a = full.sample(T, R, seed=11, early_exit=False)
+    b = ret.sample(T, R, seed=11, early_exit=False)
+    sa, sb = a["solved"].cpu().numpy() > 0, b["solved"].cpu().numpy() > 0
+    assert 3 < sa.sum() and (sa != sb).sum() <= 1
+    _host_check(batch, a["assignment"].cpu().numpy(), sa)
+    _host_check(batch, b["assignment"].cpu().numpy(), sb)
+    xa = a["assignment"].cpu().numpy().reshape(G, n)
+    xb = b["assignment"].cpu().numpy().reshape(G, n)
+    assert (np.any(xa != xb, axis=1)).sum() <= 2          # a copy differs only through a rounding-margin decision
+    again = ret.sample(T, R, seed=11, early_exit=False)
+    assert torch.equal(again["assignment"], b["assignment"]) and torch.equal(again["solved"], b["solved"])
+    with pytest.raises(_lib.DsatError, match="retire"):
+        ret.set_profile(True)                               # profiles would describe another launch sequence
+    full.set_profile(True)
+    with pytest.raises(_lib.DsatError, match="profiling"):
+        full.set_retire(True)
+    full.set_profile(False)
+
+
+def test_arena_is_not_freed_under_live_objects(rt):
+    """dsat_arena_destroy with graphs / sessions still alive in the arena does nothing (and says so);
+    runtime.Arena.close() raises; after the objects are closed both work."""
+    from diffusionsat_amd import _lib
+    from diffusionsat_amd.batch import make_batch
+    batch = make_batch([(5, [[1, -2, 3], [-1, 4], [2, 5, -3]])] * 4)
+    arena = rt.Arena(64 << 20, 8 << 20)
+    g = rt.Graph(batch, arena=arena)
+    w = rt.Weights(oracle_weights(1))
+    s = rt.Session(g, w, max_rounds=2, arena=arena)
+    with pytest.raises(_lib.DsatError, match="still alive"):
+        arena.close()
+    lib = _lib.load()
+    lib.dsat_arena_destroy(arena.handle)                   # the raw call: refused, the arena stays usable
+    assert b"still alive" in lib.dsat_last_error()
+    out = s.sample(2, 2, seed=1)
+    assert out["assignment"].shape[0] == batch.n_vars
+    torch.cuda.synchronize()
+    s.close()
+    g.close()
+    arena.reset()
+    arena.close()
+    assert arena.handle is None
+
+
 def test_samples_with_retirement_gives_the_same_dictionary(rt, tmp_path):
     """DiffusionSampler(..., retire_solved=True).samples(n) == the non-retiring sampler, on a formula with few
     models (x1 & (x2|x3) & -x4: most copies fail, some are solved at different steps) and on a tautology."""

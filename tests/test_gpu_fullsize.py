@@ -145,9 +145,10 @@ def test_facade_query_sat_and_sampler(rt, tmp_path):
     assert clear.any()
     assert np.abs(out["prediction"].cpu().numpy() - ref["prediction"])[clear].max() < 2e-4
     x = np.random.default_rng(0).standard_normal((batch.n_vars, 128)).astype(np.float32)
-    y = model.variables_output(_dev(x), gi).cpu().numpy()
+    y = model.variables_output(_dev(x)).cpu().numpy()                   # MLP.call(inputs), model/mlp.py:43
     assert np.abs(y - O.mlp(x, ws["variables_output"])).max() < 1e-4
-    yn = model.variables_norm(_dev(x), gi, 0).cpu().numpy()
+    vg = data["variables_graph_adj"]
+    yn = model.variables_norm(_dev(x), vg.multiply(1.0 / vg.sum(axis=1))).cpu().numpy()   # PairNorm.call(inputs, graph)
     assert abs(float((yn ** 2).mean()) - 1.0) < 1e-3
     # sampler: a formula every assignment of which is a model -> n samples after one batch
     cnf = tmp_path / "taut.cnf"

@@ -149,12 +149,27 @@ def test_missing_model_variables_follow_expect_partial(tmp_path):
     with pytest.raises(KeyError):
         T.load_queriesat_weights(str(tmp_path))                      # strict: no base to fall back on
     base = W.glorot_weights(99)
-    back = T.load_queriesat_weights(str(tmp_path), base=base)
+    with pytest.warns(UserWarning, match="keep their initial values"):
+        back = T.load_queriesat_weights(str(tmp_path), base=base)
     assert sorted(T.last_restore_report["missing"]) == sorted(gone)
     assert np.array_equal(back["lit_mlp"][1][0], base["lit_mlp"][1][0])           # stays at its initial value
     assert np.array_equal(back["lit_mlp"][1][1], ws["lit_mlp"][1][1])             # its bias WAS in the file
     assert np.array_equal(back["variables_output"][1][1], base["variables_output"][1][1])
     assert np.array_equal(back["update_gate"][0][0], ws["update_gate"][0][0])
+
+
+def test_checkpoint_without_model_keys_is_not_a_restore(tmp_path):
+    """A TensorBundle that holds none of an MLP's variables under the derived key names (another model, or a key
+    layout this reader does not know) must not come back as "restored" with fresh Glorot weights behind it."""
+    ws = W.glorot_weights(7)
+    foreign = {k.replace("model/", "net/"): v for k, v in _model_tensors(ws).items()}
+    write_like_tensorflow(str(tmp_path / "a"), foreign, n_shards=1)
+    with pytest.raises(KeyError, match="holds no variables of"):
+        T.load_queriesat_weights(str(tmp_path / "a"), base=W.glorot_weights(1))
+    t = {k: v for k, v in _model_tensors(ws).items() if "/update_gate/" not in k}      # one MLP wholly absent
+    write_like_tensorflow(str(tmp_path / "b"), t, n_shards=1)
+    with pytest.raises(KeyError, match="update_gate"):
+        T.load_queriesat_weights(str(tmp_path / "b"), base=W.glorot_weights(1))
 
 
 def test_rejects_foreign_and_compressed_files(tmp_path):
