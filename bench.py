@@ -151,6 +151,36 @@ def cpu_baseline(instances, ws, rounds, nodes, gpu_step=None):
                       "{1,4,8,16,32,64,all}; %.1f s in all" % (rs, rounds, ncpu, time.perf_counter() - t_all)}
 
 
+# ------------------------------------------------------------------------------------------ PMC traffic files
+def workload_key(args) -> str:
+    """What a PMC traffic file must have been measured on to describe this run's launches."""
+    if args.config == 2:
+        return "cfg2:%dx%d:R%d" % (args.graphs, args.vars, args.rounds)
+    if args.config == 3:
+        return "cfg3:%dx%d:R%d" % (args.copies, args.vars, args.rounds)
+    if args.config == 5:
+        return "cfg5:%d/%d:zipf%.2f:R%d" % (args.irr_vars, args.irr_clauses, args.zipf, args.rounds)
+    return "cfg%d" % args.config
+
+
+def load_traffic(key: str):
+    """({kernel class: HBM bytes per launch}, file name) from the newest profiles/r*_pmc_traffic*.json whose
+    `csrc_hash` is this build's and whose `workload_key` is this run's (tools/pmc_traffic.py writes both);
+    ({}, None) when there is none -- `roofline.traffic` is then null."""
+    import glob
+    from diffusionsat_amd import build
+    h = build.source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("csrc_hash") == h and d.get("workload_key") == key:
+                return {k: v["hbm_bytes_per_launch"] for k, v in d["kernels"].items()}, os.path.basename(path)
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return {}, None
+
+
 # ------------------------------------------------------------------------------------------ workloads
 def make_workload(args, rank):
     """Instances of this rank's batch (configs 2, 3, 5) and the workload description."""
@@ -178,7 +208,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed denoising steps K (default: the config's T)")
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--repeats", type=int, default=5, help="how many times the K-step timed region is run")
+    ap.add_argument("--repeats", type=int, default=None,
+                    help="how many times the K-step timed region is run (default 5; 3 for the config-4 stream)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json workload")
     ap.add_argument("--rounds", type=int, default=32)
     ap.add_argument("--graphs", type=int, default=31, help="config 2: instances per batch (31 x n=100)")
@@ -187,8 +218,9 @@ def main():
     ap.add_argument("--irr-vars", type=int, default=10000, help="config 5")
     ap.add_argument("--irr-clauses", type=int, default=60000, help="config 5")
     ap.add_argument("--zipf", type=float, default=1.3, help="config 5: popularity exponent (1.1 = heavier tail)")
-    ap.add_argument("--stream-instances", type=int, default=2048,
-                    help="config 4: instances of the stream each rank processes (the full config is 12 500 per GPU)")
+    ap.add_argument("--stream-instances", type=int, default=12500,
+                    help="config 4: instances of the stream each rank processes (the full config: 100 000 over 8 GPUs = "
+                         "12 500 per GPU, about 20 s of device time per pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -202,6 +234,8 @@ def main():
     args = ap.parse_args()
     if args.steps is None:
         args.steps = DEFAULT_STEPS[args.config]
+    if args.repeats is None:
+        args.repeats = 3 if args.config == 4 else 5
 
     # ---- launcher role: before any GPU / torch.cuda call ------------------------------------------
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -374,17 +408,10 @@ def main():
             }
             kern_name = {"round_p1_var_query_lit": "round_p1_kernel", "round_p2_clause": "round_p2_kernel<4>",
                          "round_p3_var_update": "round_p3_kernel"}
-            # HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 cannot run inside
-            # this process); null when the file is absent or the workload is not the one it was taken on
-            traffic = {}
-            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-                try:
-                    with open(os.path.join(ROOT, "profiles", name)) as f:
-                        traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
-                    break
-                except (OSError, KeyError, ValueError):
-                    continue
-            default_cfg2 = args.config == 2 and (args.graphs, args.vars) == (31, 100)
+            # HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this
+            # process).  A traffic file is tied to the kernels and the workload it was taken on: it carries the hash
+            # of csrc/ (build.source_hash) and the workload key; anything else reads as null, never as a stale number
+            traffic, traffic_src = load_traffic(workload_key(args))
             roofs = {}
             mask = sess.split_mask()
             if mask & 64:   # role D: P2's extra workgroups form the `variables` part of update_gate's first layer
@@ -418,7 +445,7 @@ def main():
                                          % (" and variables_query" if mask & 8 else "", 32 if mask & 4 else 16,
                                             "" if mask & 8 else " / variables_query")) if a2
                                         else "v_mfma_f32_16x16x4_f32",
-                                "traffic": traffic.get(k) if default_cfg2 else None,
+                                "traffic": traffic.get(k), "traffic_source": traffic_src if k in traffic else None,
                                 "avg_launch_us": us,
                                 "launches_per_step": prof[k]["launches"] / steps_prof,
                                 "algorithmic_flops_per_launch": fl,

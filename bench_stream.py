@@ -1,7 +1,7 @@
 """bench.py --config 4: the NeuroSAT-style SR(n) stream (BASELINE.json configs[3]; data/k_sat.py).
 
-Every rank takes its share of a 100 000-instance stream (`--stream-instances` of them; the full
-config is 12 500 per GPU at 8 GPUs), batches it to the reference's 20 000-node budget
+Every rank takes its share of a 100 000-instance stream (`--stream-instances` of them; default = the full
+config's 12 500 per GPU), batches it to the reference's 20 000-node budget
 (`batch.batch_by_node_budget`, data/dimac.py:267-293) and samples every batch for T=32 denoising
 steps through `diffusionsat_amd.stream.StreamSampler`: two pooled slots, the host set-up of batch
 i+1 (CSR build, upload, session, hipGraph capture) overlapped with batch i on the device.
@@ -104,12 +104,16 @@ def run_stream_bench(args, rank, world, dev, wts, ws, barrier, gather_floats):
     if not args.no_profile:
         # A/B: the same stream without pooling (dsat_graph_create / dsat_session_create + hipFree per batch),
         # and strictly one batch at a time (host set-up exposed)
-        ab = {}
-        for name, pooled, slots in (("unpooled_two_slots", False, 2), ("pooled_one_slot", True, 1),
-                                    ("unpooled_one_slot", False, 1)):
+        # (on a bounded sample of the stream, its first 48 batches: the default run must stay within minutes)
+        ab = {"batches": min(len(batches), 48)}
+        full = batches
+        batches = batches[:48]
+        for name, pooled, slots in (("pooled_two_slots", True, 2), ("unpooled_two_slots", False, 2),
+                                    ("pooled_one_slot", True, 1), ("unpooled_one_slot", False, 1)):
             r = stream_once(pooled, slots, seed=99, collective=False)
             ab[name] = {"value": len(batches) * T / r["elapsed"],
                         "host_setup_ms_median": float(np.median(r["host_setup_ms"]))}
+        batches = full
         result["stream"]["ab"] = ab
         # roofline of the dominant kernel on the stream's median-size batch (eager profiling pass)
         b = batches[int(np.argsort(nodes)[len(nodes) // 2])]

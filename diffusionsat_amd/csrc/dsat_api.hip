@@ -562,8 +562,11 @@ extern "C" int dsat_graph_info(const dsat_graph* g, int32_t* n_vars, int32_t* n_
 static inline uint16_t bf16_rne_host(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    const uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
+    // a finite weight within half a bf16 ulp of the format's end would round to infinity: truncate it instead (the
+    // residual slices then carry the rest, still exactly -- weights are finite, dsat_weights_load checks)
+    if ((r & 0x7F800000u) == 0x7F800000u && (u & 0x7F800000u) != 0x7F800000u) return (uint16_t)(u >> 16);
+    return (uint16_t)(r >> 16);
 }
 static inline float bf16_to_float_host(uint16_t h) {
     const uint32_t u = (uint32_t)h << 16;
@@ -755,6 +758,7 @@ static const char* kKernelClassNames[KC_COUNT] = {
 
 struct dsat_session {
     int device = -1;
+    int n_cus = 256;               // hipDeviceAttributeMultiprocessorCount of `device` (launch planning: one workgroup per CU)
     dsat_arena* arena = nullptr;   // non-null: the workspace slab is carved from this arena
     const dsat_graph* g = nullptr;
     const dsat_weights* w = nullptr;
@@ -2403,6 +2407,45 @@ static int op_mlp_fused(dsat_session* s, int mlp, const float* x, int rows, floa
     return DSAT_OK;
 }
 
+// impl 2: the split-product chain (kernels_split_op.hip): input packed like op_mlp_fused, weights = the bf16 planes
+static int op_mlp_split(dsat_session* s, int mlp, const float* x, int rows, float* y, int rb, hipStream_t st) {
+    const auto& layers = s->w->mlp[mlp];
+    DSAT_REQUIRE(layers.size() >= 2 && layers.size() <= 3, DSAT_E_UNSUPPORTED,
+                 "dsat_op_mlp_ex(impl=2): the split-product chain takes MLPs of 2 or 3 layers");
+    for (const PackedLayer& pl : layers)
+        DSAT_REQUIRE(pl.ntiles() <= ROUND_NWAVES, DSAT_E_UNSUPPORTED,
+                     "dsat_op_mlp_ex(impl=2): a layer wider than 256 columns (one 16-column tile per wave)");
+    DSAT_REQUIRE(rb == 1 || rb == 2 || rb == 4, DSAT_E_INVALID, "dsat_op_mlp_ex(impl=2): rb must be 1, 2 or 4");
+    auto blocks = first_layer_blocks(mlp);
+    int k[5] = {0, 0, 0, 0, 0}, kp[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < blocks.size(); ++i) { k[i] = blocks[i].k; kp[i] = blocks[i].kp; }
+    const int kpad = layers[0].kpad;
+    const int64_t n = (int64_t)rows * kpad;
+    hipLaunchKernelGGL(dsat::pack_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x,
+                       layers[0].in_dim, s->scratch, kpad, rows, (int)blocks.size(), k[0], kp[0], k[1], kp[1],
+                       k[2], kp[2], k[3], kp[3], k[4], kp[4]);
+    SplitOpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nlayers = (int)layers.size();
+    a.ldh = 16;
+    for (int l = 0; l < a.nlayers; ++l) {
+        a.ws[l] = reinterpret_cast<const uint4*>(layers[l].ws);
+        a.bias[l] = layers[l].bias;
+        a.ks[l] = layers[l].ksteps();
+        a.nt[l] = layers[l].ntiles();
+        if (l > 0) a.ldh = std::max(a.ldh, layers[l].ksteps() * 32 + 16);
+    }
+    for (int l = a.nlayers; l < 3; ++l) { a.ws[l] = a.ws[0]; a.bias[l] = a.bias[0]; a.ks[l] = a.ks[0]; a.nt[l] = 0; }
+    a.x = s->scratch; a.kpad0 = kpad; a.rows = rows;
+    a.ld_in = layers[0].ksteps() * 32 + 16;
+    a.y = y; a.ldy = layers.back().out_dim; a.ncols_y = layers.back().out_dim;
+    hipError_t e = launch_split_op(a, rb, st);
+    DSAT_REQUIRE(e != hipErrorInvalidValue, DSAT_E_UNSUPPORTED,
+                 "dsat_op_mlp_ex(impl=2): the tile's plane images do not fit the CU's LDS at this rb");
+    DSAT_HIP(e);
+    return DSAT_OK;
+}
+
 extern "C" int dsat_op_mlp_ex(dsat_session* s, int32_t mlp, const float* x, int32_t rows, float* y,
                               int32_t impl, int32_t rb, int32_t nwaves, void* stream) {
     if (impl == 0) return dsat_op_mlp(s, mlp, x, rows, y, stream);
@@ -2414,6 +2457,7 @@ extern "C" int dsat_op_mlp_ex(dsat_session* s, int32_t mlp, const float* x, int3
     const int cap = (mlp == DSAT_MLP_CLAUSE) ? std::max(s->g->C, 1) : s->g->N;
     DSAT_REQUIRE(rows >= 0 && rows <= cap, DSAT_E_INVALID, "dsat_op_mlp_ex: rows exceed the session's capacity");
     if (rows == 0) return DSAT_OK;
+    if (impl == 2) return op_mlp_split(s, mlp, x, rows, y, rb, (hipStream_t)stream);
     return op_mlp_fused(s, mlp, x, rows, y, rb, nwaves, (hipStream_t)stream, true);
 }
 

@@ -180,6 +180,20 @@ struct ChainArgs {
 };
 hipError_t launch_chain(const ChainArgs& a, int rb, int nwaves, hipStream_t st);
 
+// ---- stand-alone split-product chain (kernels_split_op.hip; dsat_op_mlp_ex impl 2) -------------------
+struct SplitOpArgs {
+    const uint4* ws[3];     // per layer: weights as three bf16 planes in fragment order (PackedLayer::ws)
+    const float* bias[3];
+    int ks[3], nt[3];       // k-steps of 32 and 16-column tiles per layer (nt <= 16: one tile per wave)
+    int nlayers;            // 2 or 3
+    const float* x;         // [rows][kpad0] packed input (blocks padded)
+    int kpad0, rows;
+    int ld_in, ldh;         // row strides of the plane images in LDS, bf16 elements
+    float* y;
+    int ldy, ncols_y;
+};
+hipError_t launch_split_op(const SplitOpArgs& a, int rb, hipStream_t st);
+
 // ---- fused round kernels (kernels_round.hip) ---------------------------------------------
 // One message-passing round = three row-tile kernels (+ the select/SAT kernel):
 //   P1 var tile   : finish PairNorm of the previous round (R13), output MLP + logits of the

@@ -17,10 +17,11 @@ import torch.distributed as dist
 from .batch import Instance, instance_size, sat_node_count
 
 
-def broadcast_weight_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
+def broadcast_weight_blob(blob: torch.Tensor, src: int = 0, force: bool = False) -> torch.Tensor:
     """Rank ``src`` holds the flat fp32 weight blob (weights.to_blob); afterwards every rank does.
-    One 3.4 MB broadcast: latency-bound, outside any timed region."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    One 3.4 MB broadcast: latency-bound, outside any timed region.  ``force``: issue the collective even in a
+    world of one rank (the one-GPU test that proves RCCL loads and runs on the box, tests/test_gpu_rccl.py)."""
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size() > 1):
         dist.broadcast(blob, src=src)
     return blob
 

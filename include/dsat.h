@@ -252,7 +252,10 @@ int dsat_op_mlp(dsat_session* s, int32_t mlp, const float* x, int32_t rows, floa
                 void* stream);
 /* Same operator with the implementation chosen explicitly: impl 0 = one GEMM launch per Dense
  * layer (kernels_gemm.hip), impl 1 = row-tile fused chain (kernels_chain.hip) with 16*rb rows
- * per workgroup and `nwaves` wavefronts (rb in {1,2,4}, nwaves in {4,8}). */
+ * per workgroup and `nwaves` wavefronts (rb in {1,2,4}, nwaves in {4,8}), impl 2 = the same chain with every
+ * fp32 product formed from bf16 slices on the bf16 matrix pipe (kernels_split_op.hip: the split_chain the round
+ * kernels run, 16 wavefronts, rb in {1,2,4}; MLPs of 2-3 layers of at most 256 columns, i.e. all but lit_mlp;
+ * DSAT_E_UNSUPPORTED otherwise). */
 int dsat_op_mlp_ex(dsat_session* s, int32_t mlp, const float* x, int32_t rows, float* y,
                    int32_t impl, int32_t rb, int32_t nwaves, void* stream);
 /* Measurement helper: average device time in microseconds of `iters` back-to-back runs of

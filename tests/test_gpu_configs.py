@@ -204,6 +204,28 @@ def test_config5_size_properties(rt, monkeypatch):
     _host_check(batch, out["assignment"].cpu().numpy(), out["solved"].cpu().numpy() > 0)
 
 
+def test_config5_full_T128_sampler(rt):
+    """BASELINE config 5 as stated: T = 128 denoising steps x R = 32 rounds on the 80 000-node irregular formula
+    (about 1.3 s of device time).  The whole run twice: bitwise the same assignment, predictions of every step and
+    solved flag (determinism over 4 096 rounds of the heavy-row / level-2-sum machinery), every prediction finite,
+    and the solved flag re-checked on the host."""
+    from diffusionsat_amd.batch import make_batch
+    from diffusionsat_amd.instances import irregular_cnf
+    batch = make_batch([irregular_cnf(10000, 60000, seed=5, zipf_a=1.3)[:2]])
+    assert batch.n_nodes == 80000
+    s = rt.Session(rt.Graph(batch), rt.Weights(oracle_weights(3)), max_rounds=32)
+    a = s.sample(128, 32, seed=7, early_exit=True, want_predictions=True)
+    b = s.sample(128, 32, seed=7, early_exit=True, want_predictions=True)
+    torch.cuda.synchronize()
+    assert a["predictions"].shape == (128, batch.n_vars) and torch.isfinite(a["predictions"]).all()
+    assert torch.equal(a["predictions"], b["predictions"])
+    assert torch.equal(a["assignment"], b["assignment"]) and torch.equal(a["solved"], b["solved"])
+    assert a["predictions"][0].ne(a["predictions"][127]).any()          # the steps really differ (noise scale falls)
+    _host_check(batch, a["assignment"].cpu().numpy(), a["solved"].cpu().numpy() > 0)
+    c = s.sample(128, 32, seed=8, early_exit=True, want_predictions=True)
+    assert c["predictions"].ne(a["predictions"]).any()                  # another seed, another trajectory
+
+
 def test_large_graph_select_parts_and_early_exit(rt):
     """One formula large enough to be cut into several select/SAT workgroups (more than 4096 clauses),
     spread over enough tiles for the level-2 PairNorm sums, with one literal in thousands of clauses:

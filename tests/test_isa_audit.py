@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("src", ["kernels_round.hip", "kernels_chain.hip"])
+@pytest.mark.parametrize("src", ["kernels_round.hip", "kernels_chain.hip", "kernels_split_op.hip"])
 def test_no_instruction_touches_a_register_with_a_load_in_flight(src):
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not on PATH")

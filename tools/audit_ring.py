@@ -27,7 +27,7 @@ def regs(tok):
 
 
 total_bad = 0
-for m in re.finditer(r"^(_ZN4dsat\S*(?:round_p\d|chain_kernel)\S*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
+for m in re.finditer(r"^(_ZN4dsat\S*(?:round_p\d|chain_kernel|split_op_kernel)\S*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
     name, lines = m.group(1), m.group(2).split("\n")
     fifo = []          # entries: set of registers being written (empty for stores / compiler loads)
     in_asm, bad, nasm, prev_op = False, [], 0, ""
