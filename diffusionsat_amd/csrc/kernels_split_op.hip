@@ -17,7 +17,7 @@ __global__ __launch_bounds__(1024) void split_op_kernel(SplitOpArgs a) {
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
     unsigned short* hA = xs + 3 * ROWS * a.ld_in;
-    unsigned short* hB = hA + 3 * ROWS * a.ldh;
+    unsigned short* hB = a.nlayers > 2 ? hA + 3 * ROWS * a.ldh : hA;   // a 2-layer chain has one hidden tile
     const int r0 = blockIdx.x * ROWS;
     const float* x = a.x;
     const int kpad0 = a.kpad0, rows = a.rows, ld_in = a.ld_in;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(1024) void split_op_kernel(SplitOpArgs a) {
 hipError_t launch_split_op(const SplitOpArgs& a, int rb, hipStream_t st) {
     if (a.rows <= 0) return hipSuccess;
     const int rows_per = 16 * rb;
-    const size_t need = (size_t)3 * rows_per * (a.ld_in + 2 * (size_t)a.ldh) * 2;
+    const size_t need = (size_t)3 * rows_per * (a.ld_in + (a.nlayers > 2 ? 2 : 1) * (size_t)a.ldh) * 2;
     if (need > (size_t)ROUND_LDS_FLOATS * 4) return hipErrorInvalidValue;
     const dim3 grid((a.rows + rows_per - 1) / rows_per), block(1024);
     if (rb == 1) hipLaunchKernelGGL(split_op_kernel<1>, grid, block, 0, st, a);

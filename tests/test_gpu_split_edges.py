@@ -62,7 +62,9 @@ def test_op_mlp_ex_split_chain(rt, mlp, rb):
     try:
         y = s.op_mlp(mlp, _dev(x), impl=2, rb=rb).cpu().numpy()
     except _lib.DsatError as e:
-        assert "LDS" in str(e) and rb == 4 and mlp in (2, 3)        # 64-row plane images of the 384 / 528-wide inputs
+        # the plane images of a 32- / 64-row tile of the 384- and 528-wide inputs exceed the CU's 160 KiB: refused,
+        # not run; 16-row tiles always fit
+        assert "LDS" in str(e) and ((mlp == 3 and rb >= 2) or (mlp == 2 and rb == 4)), (mlp, rb, str(e))
         return
     ref, scale = _ref64(x, ws[name]), _scale64(x, ws[name])
     assert np.all(np.isfinite(y))
