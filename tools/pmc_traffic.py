@@ -19,16 +19,16 @@ NAMES = {"round_p1_kernel": "round_p1_var_query_lit", "round_p2_kernel": "round_
 
 
 def collect(d, counter):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from pmc_report import rows_of          # CSV or rocpd database, whichever the pass wrote
     vals = {}
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        with open(f, newline="") as fh:
-            for row in csv.DictReader(fh):
-                if row["Counter_Name"] != counter:
-                    continue
-                for k, nm in NAMES.items():
-                    if k in row["Kernel_Name"]:
-                        # the tail launch of P1 (output MLP only) would drag the median of P1 down
-                        vals.setdefault(nm, []).append(float(row["Counter_Value"]))
+    for row in rows_of(d):
+        if row["Counter_Name"] != counter:
+            continue
+        for k, nm in NAMES.items():
+            if k in row["Kernel_Name"]:
+                # (median: the tail launch of P1 -- output MLP only -- would drag a mean of P1 down)
+                vals.setdefault(nm, []).append(float(row["Counter_Value"]))
     return vals
 
 
