@@ -1140,6 +1140,33 @@ static bool plan_round(dsat_session* s) {
             }
             if (getenv("DSAT_DEBUG_PLAN") != nullptr)
                 fprintf(stderr, "[dsat] P1 role B query chain as split products: %d\n", r.sp_ws[0] != nullptr);
+            // ... and variables_output (round 2 left it on the fp32 MFMA: 18.5 k of the role-B workgroup's 62.6 k cycles).
+            // Needs the query chain as split products too (the LDS plan below is shared): [X fp32 | output planes |
+            // output hidden planes | mean]; the query chain's v1 planes then end where the hidden planes ended and its
+            // hidden planes start at 0, over X (sliced by then).  DSAT_P1_BOSPLIT=0 keeps the fp32-MFMA output chain.
+            const auto& ol = w->mlp[DSAT_MLP_VARIABLES_OUTPUT];
+            const char* swo = getenv("DSAT_P1_BOSPLIT");
+            if (r.sp_ws[0] != nullptr && ol.size() == 2 && ol[0].kpad == F && r.mout4.L[0].ntiles <= ROUND_NWAVES &&
+                r.mout4.L[1].ntiles <= ROUND_NWAVES && r.mout4.L[0].ntiles * 16 <= ol[1].ksteps() * 32 &&
+                !(swo != nullptr && swo[0] == '0')) {
+                const int ldo = std::max(ol[0].ksteps(), ol[1].ksteps()) * 32 + 16;
+                const int xo_f = 3 * 64 * ldo * 2 / 4, x_f = 64 * r.ld_x;                 // floats
+                const int xq_f = 3 * 64 * r.s_ld_seg * 2 / 4, hq_f = 3 * 64 * r.s_ld_hid * 2 / 4;
+                const int mean_at = LDS - mean_floats;
+                const int end_o = x_f + 2 * xo_f;                                           // end of the output chain's planes
+                const int xq_at = std::max(end_o, x_f + xq_f) - xq_f;                      // v1 planes: behind X, ending with them
+                if (end_o <= mean_at && xq_at + xq_f <= mean_at && hq_f <= xq_at && xq_at >= x_f) {
+                    for (int l = 0; l < 2; ++l) {
+                        r.bo_ws[l] = reinterpret_cast<const uint4*>(ol[l].ws);
+                        r.bo_ks[l] = ol[l].ksteps();
+                        r.bo_nt[l] = r.mout4.L[l].ntiles;
+                    }
+                    r.bo_ld = ldo;
+                    r.bo_off_x = x_f; r.bo_off_h = x_f + xo_f; r.bo_off_xq = xq_at; r.bo_off_mean = mean_at;
+                }
+            }
+            if (getenv("DSAT_DEBUG_PLAN") != nullptr)
+                fprintf(stderr, "[dsat] P1 role B output chain as split products: %d\n", r.bo_ws[0] != nullptr);
         }
         // role A on 32-row tiles with lit_mlp as split products (kernels_round.hip, role_a2): the released
         // 137 -> 512 -> 512 -> 256 shape, role B present (it then covers every 64-row group)
@@ -2630,7 +2657,8 @@ static bool role_d_on(const dsat_session* s) {   // for the whole batch, select 
 extern "C" int32_t dsat_session_split_mask(const dsat_session* s) {
     if (s == nullptr || !s->use_fused) return 0;
     return (s->p2_split ? 1 : 0) | (s->p3_split ? 2 : 0) | (s->p1_a2 ? 4 : 0) | (s->ra1.sp_ws[0] != nullptr && s->pair_blocks ? 8 : 0) |
-           (s->p3_split && s->p3_bm == 32 ? 16 : 0) | (s->p1_a1s && !s->p1_a2 ? 32 : 0) | (role_d_on(s) ? 64 : 0);
+           (s->p3_split && s->p3_bm == 32 ? 16 : 0) | (s->p1_a1s && !s->p1_a2 ? 32 : 0) | (role_d_on(s) ? 64 : 0) |
+           (s->ra1.bo_ws[0] != nullptr && s->pair_blocks ? 128 : 0);
 }
 
 extern "C" int64_t dsat_session_packed_bytes(const dsat_session* s, int32_t* offsets_out) {

@@ -294,6 +294,12 @@ struct RoundArgs {
     const uint4* d_ws;
     float* upd_part;
     const uint4* a2_ws[3];  // lit_mlp's three layers as bf16 slices
+    // P1 role B: variables_output (128 -> 128 -> 8) as split products as well: the PairNorm of the 64-row tile emits the
+    // pre-mix state as planes.  bo_ws[0] == nullptr: the fp32-MFMA chain (mout4).  LDS plan in float offsets: input
+    // planes, hidden planes, the query chain's v1 planes afterwards, the PairNorm means; bo_ld: row stride, bf16 elements
+    const uint4* bo_ws[2];
+    int bo_ks[2], bo_nt[2];
+    int bo_off_x, bo_off_h, bo_off_xq, bo_off_mean, bo_ld;
     // P2 / P3 with fp32 products formed from bf16 slices (round_p2s_kernel, round_p3s_kernel, split_bf16.h): per
     // layer the weights as three bf16 planes in fragment order, k-steps of 32 and column tiles; LDS plan in
     // BYTES / bf16 elements (P3: s_buf1 = the input planes, s_buf2 = hidden A then hidden B)

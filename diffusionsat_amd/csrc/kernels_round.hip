@@ -164,7 +164,10 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
                                               const float* __restrict__ state_in, float* __restrict__ state_out,
                                               bool first, float* sState, int ldS,
                                               float* sLogit, int ldL, float* sMean, float* sPart, int ldP, int tid,
-                                              float inv_f = 1.f / F, int fm = F) {
+                                              float inv_f = 1.f / F, int fm = F, unsigned short* pLogit = nullptr,
+                                              int ldPL = 0) {
+    // pLogit (role B of P1 with variables_output as split products): the pre-mix value goes out as three bf16
+    // planes [3][BM][ldPL] (split_bf16.h) instead of the fp32 tile sLogit
     // inv_f = 1 / feature_maps, fm = feature_maps: narrower states live zero-padded in the 128-wide rows
     // state_in: the carried state of the previous round; state_out: where this round's goes (nullptr:
     // another workgroup normalises the same rows and owns the write).  sMean: F floats; sPart: NT/F rows
@@ -176,6 +179,7 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
     for (int r = tile_hi - tile_lo + hw; r < BM; r += NT / 32) {
         st4(sState + r * ldS + sub * 4, make_float4(0.f, 0.f, 0.f, 0.f));
         if (sLogit != nullptr) st4(sLogit + r * ldL + sub * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+        if (pLogit != nullptr) split_zero4(pLogit, BM * ldPL, r * ldPL + sub * 4);
     }
     if (first) {   // query_sat.py:141, :148: both states start as ones
         const float4 one = make_float4(sub * 4 + 0 < fm ? 1.f : 0.f, sub * 4 + 1 < fm ? 1.f : 0.f,
@@ -239,6 +243,7 @@ __device__ __forceinline__ void pairnorm_tile(int tile_lo, int rows, const TileM
                 res.x = v.x * rs * 0.25f + 0.1f * o4.x; res.y = v.y * rs * 0.25f + 0.1f * o4.y;
                 res.z = v.z * rs * 0.25f + 0.1f * o4.z; res.w = v.w * rs * 0.25f + 0.1f * o4.w;
                 if (sLogit != nullptr) st4(sLogit + (r - tile_lo) * ldL + sub * 4, res);
+                if (pLogit != nullptr) split_st4(pLogit, BM * ldPL, (r - tile_lo) * ldPL + sub * 4, res);
                 res.x = __fadd_rn(__fmul_rn(res.x, 0.2f), __fmul_rn(res.x, 0.8f));
                 res.y = __fadd_rn(__fmul_rn(res.y, 0.2f), __fmul_rn(res.y, 0.8f));
                 res.z = __fadd_rn(__fmul_rn(res.z, 0.2f), __fmul_rn(res.z, 0.8f));
@@ -767,8 +772,21 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
             const int n = tile_lo + tid;
             load_aux_row(sX + tid * ldx + F, a.aux, n, N, a.round, n < N && !a.tail);
         }
+#if DSAT_ROUND_NWAVES == 16
+        // variables_output as split products too (bo_ws): the pre-mix state leaves the PairNorm as planes, so the LDS
+        // plan is [X | out-planes | out-hidden | mean] and the query chain's planes go over all of it afterwards
+        const bool out_split = a.bo_ws[0] != nullptr;
+        unsigned short* xo = reinterpret_cast<unsigned short*>(smem + a.bo_off_x);
+        unsigned short* ho = reinterpret_cast<unsigned short*>(smem + a.bo_off_h);
+        if (out_split) sMean = smem + a.bo_off_mean;
+        pairnorm_tile<BM4>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, nullptr,
+                           a.round == 0, sX, ldx, out_split ? nullptr : sVlog, ldv, sMean, sMean + F, F, tid, a.inv_f, a.fm,
+                           out_split ? xo : nullptr, a.bo_ld);
+#else
+        constexpr bool out_split = false;
         pairnorm_tile<BM4>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, nullptr,
                            a.round == 0, sX, ldx, sVlog, ldv, sMean, sMean + F, F, tid, a.inv_f, a.fm);
+#endif
         auto store_logits = [=](int row, int col, float4 v) {
             int n = tile_lo + row;
             NO_HOIST(n);
@@ -794,6 +812,18 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
         // fragment (side by side on half the waves each, as the 16-row pair runs them, the query half
         // needs two column tiles per wave: more registers than a 1024-thread workgroup has)
         DSAT_STAMP(a, 1);
+#if DSAT_ROUND_NWAVES == 16
+        if (out_split) {
+            if (a.round > 0) {
+                SplitChain so;
+                so.nlayers = 2;
+#pragma unroll
+                for (int l = 0; l < 3; ++l) so.L[l] = SplitLayer{a.bo_ws[l < 2 ? l : 0], a.mout4.L[l < 2 ? l : 0].bias, a.bo_ks[l < 2 ? l : 0], a.bo_nt[l < 2 ? l : 0]};
+                const int wvo = __builtin_amdgcn_readfirstlane(wave);
+                split_chain<4, NT, DSAT_SPLIT_PD4>(so, xo, a.bo_ld, ho, ho, a.bo_ld, wvo, lane, tid, store_logits, [] {});
+            }
+        } else
+#endif
         if (a.round > 0) run_chain<4>(a.mout4, sVlog, ldv, sA, a.b_ld_a, sB, a.b_ld_b, wave, lane, store_logits);
         DSAT_STAMP(a, 2);
         // (the tail launch -- role B runs in it when role A is on 32-row tiles -- is the output half alone)
@@ -801,7 +831,9 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
         if (!a.tail && a.sp_ws[0] != nullptr) {
             // variables_query with split products (split_bf16.h): v1 as slices goes where the output chain's tiles were
             // (sVlog | sA, dead now), the hidden planes over the fp32 v1 rows and the unused second buffer (sX | sB)
-            unsigned short* xp = reinterpret_cast<unsigned short*>(sVlog);
+            // (with the output chain on planes: v1 planes at the end of the region its planes occupied, hidden planes from
+            // the start of the workgroup's LDS, over X once it has been sliced)
+            unsigned short* xp = out_split ? reinterpret_cast<unsigned short*>(smem + a.bo_off_xq) : reinterpret_cast<unsigned short*>(sVlog);
             unsigned short* hp = reinterpret_cast<unsigned short*>(sX);
             const int ldp = a.s_ld_seg;
             for (int i = tid; i < BM4 * (ldp - 16) / 4; i += NT) {

@@ -344,12 +344,13 @@ int dsat_session_profile(dsat_session* s, int32_t cap, const char** names, doubl
 /* Which arithmetic the round kernels of this session run their MLPs (model/mlp.py:42-50) in: bit 0 set = the
  * clause tile (P2), bit 1 set = the variable-update tile (P3), bit 2 set = lit_mlp of P1 on 32-row tiles, bit 5
  * set = lit_mlp of P1 on 16-row tiles (bit 3: role B's variables_query, bit 4: P3 on 32-row tiles; bit 6: the
- * `variables` part of update_gate's first layer is formed ahead of P3 by extra workgroups of P2 when CUs are idle) form
+ * `variables` part of update_gate's first layer is formed ahead of P3 by extra workgroups of P2 when CUs are idle; bit 7:
+ * role B's variables_output) form
  * every fp32 product from three bf16 slices
  * per operand on the bf16 matrix pipe (six slice products, fp32 accumulation: fp32-level error, see
  * diffusionsat_amd/csrc/split_bf16.h); clear = v_mfma_f32_16x16x4_f32.  The environment variables
- * DSAT_P2_SPLIT=0 / DSAT_P3_SPLIT=0 / DSAT_P1_ASPLIT=0 / DSAT_P1_BSPLIT=0 at session creation select the fp32-MFMA
- * form. */
+ * DSAT_P2_SPLIT=0 / DSAT_P3_SPLIT=0 / DSAT_P1_ASPLIT=0 / DSAT_P1_BSPLIT=0 (/ DSAT_P1_BOSPLIT=0 for role B's output
+ * chain alone) at session creation select the fp32-MFMA form. */
 int32_t dsat_session_split_mask(const dsat_session* s);
 /* Several batches in flight on one GPU (a stream of batches, satuniformity/DiffusionSampler.py:283-307 with n > one
  * batch; data/dimac.py:267-293): prefer CU-cycles over the latency of one batch.  Today this runs lit_mlp

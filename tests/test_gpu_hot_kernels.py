@@ -78,7 +78,7 @@ def _session(rt, batch, ws, max_rounds, fused):
     if fused == "fused_f32mfma":
         assert s.split_mask() == 0
     if fused == "fused":
-        assert s.split_mask() & 67 == 67    # the released layout runs both split-product tiles, and role D of P2
+        assert s.split_mask() & 203 == 203    # the released layout: both split-product tiles, role B's two chains, role D of P2
     if fused == "fused_a2":
         assert s.split_mask() & 23 == 23      # ... and P3 on 32-row tiles
     return s
