@@ -65,6 +65,7 @@ SIGNATURES = {
     "dsat_session_create": (C.c_int, [_vp, _vp, _i32, _pp]),
     "dsat_session_destroy": (None, [_vp]),
     "dsat_session_set_graph_replay": (C.c_int, [_vp, _i32]),
+    "dsat_session_set_supervised": (C.c_int, [_vp, _i32]),
     "dsat_diffusion_step": (C.c_int, [_vp, _f32, _vp, _vp, _vp, _u64, _u32, _i32, _i32,
                                        _vp, _vp, _vp, _vp, _vp, _vp]),
     "dsat_diffusion_step_self": (C.c_int, [_vp, _f32, _vp, _vp, _vp, _vp, _u64, _u32, _i32, _i32,

@@ -767,6 +767,7 @@ struct dsat_session {
     dsat_tap tap;                  // dsat_session_set_tap (parity tests)
     // early retirement of solved copies (dsat_session_set_retire)
     int retire = 0;
+    int unsupervised = 0;          // dsat_session_set_supervised(s, 0): QuerySAT(supervised=False) selection
     int32_t *lid = nullptr, *move_src = nullptr, *n_act_dev = nullptr;
     float *x0b = nullptr, *x1b = nullptr;   // second x buffers (the survivors move between steps)
     int32_t* n_act_host = nullptr;          // pinned
@@ -1675,6 +1676,12 @@ extern "C" int dsat_session_set_retire(dsat_session* s, int32_t enable) {
     return DSAT_OK;
 }
 
+extern "C" int dsat_session_set_supervised(dsat_session* s, int32_t supervised) {
+    DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_supervised: null session");
+    s->unsupervised = supervised ? 0 : 1;   // lives in the device control block: captured graphs need no rebuild
+    return DSAT_OK;
+}
+
 extern "C" int dsat_session_set_profile(dsat_session* s, int32_t enable) {
     DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_profile: null session");
     DSAT_REQUIRE(!(enable && s->retire), DSAT_E_STATE,
@@ -2162,6 +2169,7 @@ static int diffusion_step_impl(dsat_session* s, float noise_scale, const float* 
     const size_t N = s->g->N;
     DSAT_HIP(hipMemcpyAsync(s->in_noisy, noisy_num, N * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
     Ctl c = base_ctl(noise_scale, step_index, 1, rounds, seed);
+    c.unsupervised = s->unsupervised;
     if (normal) {
         DSAT_HIP(hipMemcpyAsync(s->in_normal, normal, (size_t)rounds * N * 4 * sizeof(float),
                                 hipMemcpyDeviceToDevice, st));
@@ -2232,6 +2240,7 @@ static int sample_retire_impl(dsat_session* s, int32_t n_steps, int32_t rounds, 
     const int G = g->G, np = g->N / G;
     const size_t N = g->N;
     Ctl c = base_ctl(1.f, 0, n_steps, rounds, seed);
+    c.unsupervised = s->unsupervised;
     c.inj_normal = normal; c.normal_step_stride = (int64_t)rounds * N * 4;
     c.inj_labels = labels; c.labels_step_stride = (int64_t)N;
     c.inj_uniform = uniform; c.uniform_step_stride = (int64_t)N;
@@ -2299,6 +2308,7 @@ static int sample_impl(dsat_session* s, int32_t n_steps, int32_t rounds, uint64_
     const dsat_graph* g = s->g;
     const size_t N = g->N;
     Ctl c = base_ctl(1.f, 0, n_steps, rounds, seed);
+    c.unsupervised = s->unsupervised;
     c.inj_normal = normal; c.normal_step_stride = (int64_t)rounds * N * 4;
     c.inj_labels = labels; c.labels_step_stride = (int64_t)N;
     c.inj_uniform = uniform; c.uniform_step_stride = (int64_t)N;

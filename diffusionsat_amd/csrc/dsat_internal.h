@@ -149,7 +149,41 @@ struct Ctl {
     // on which slot it sits in.  lid == nullptr: slot == original position.
     const int32_t* lid;
     int32_t n_per;               // variables per copy
+    // QuerySAT(supervised=False): the logit map of a graph is chosen by the unsupervised clause loss of its own
+    // clauses (model/query_sat.py:293-309 with use_linear_loss = False) instead of the KL to the labels (:289-292)
+    int32_t unsupervised;
 };
+
+// softplus_mixed_loss_adj (loss/sat.py:92-100) of clause c for each of the eight logit maps, added to acc:
+// val = exp(-sum_lit softplus(+-logit)); loss = val * -(log(1 - val + 1e-8) - log(1 + 1e-8)).  In fp32 1 + 1e-8 is 1
+// (as in the reference's float32 graph), so the second logarithm is zero.
+__device__ __forceinline__ void unsup_clause_loss8(const float* __restrict__ logits, const int32_t* __restrict__ rowptr,
+                                                   const int32_t* __restrict__ c_lit, int c, int N,
+                                                   float (&acc)[LOGIT_MAPS]) {
+    float S[LOGIT_MAPS];
+#pragma unroll
+    for (int k = 0; k < LOGIT_MAPS; ++k) S[k] = 0.f;
+    for (int e = rowptr[c]; e < rowptr[c + 1]; ++e) {
+        const int l = c_lit[e];
+        const int v = l < N ? l : l - N;
+        const float sgn = l < N ? 1.f : -1.f;
+        const float4 l0 = *reinterpret_cast<const float4*>(logits + (size_t)v * LOGIT_MAPS);
+        const float4 l1 = *reinterpret_cast<const float4*>(logits + (size_t)v * LOGIT_MAPS + 4);
+        const float lg[LOGIT_MAPS] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+        for (int k = 0; k < LOGIT_MAPS; ++k) {
+            const float x = sgn * lg[k];
+            S[k] += fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));       // tf.nn.softplus
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LOGIT_MAPS; ++k) {
+        const float val = expf(-S[k]);
+        acc[k] += val * -(logf((1.f - val) + 1e-8f) - logf(1.f + 1e-8f));
+    }
+}
+// per_graph_loss of the unsupervised branch from the graph's sum (:309)
+__device__ __forceinline__ float unsup_graph_loss(float sum) { return sqrtf(sum + 1e-6f) - sqrtf(1e-6f); }
 
 // original (logical) index of variable v of the active prefix
 __device__ __forceinline__ int logical_var(const Ctl* ctl, int v) {

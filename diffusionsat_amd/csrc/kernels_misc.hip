@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void select_kernel(
     const int32_t* __restrict__ seg, const float* __restrict__ logits,
     const int32_t* __restrict__ labels, Ctl* __restrict__ ctl, float* __restrict__ pgl,
     int32_t* __restrict__ best, float* __restrict__ out_logits, uint8_t* __restrict__ assign,
-    int32_t* __restrict__ graph_unsat) {
+    int32_t* __restrict__ graph_unsat, const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ c_lit, int N) {
     if (ctl->done != 0) return;
     __shared__ float red[256][LOGIT_MAPS + 1];
     __shared__ int s_best;
@@ -255,7 +256,10 @@ __global__ __launch_bounds__(256) void select_kernel(
     float acc[LOGIT_MAPS];
 #pragma unroll
     for (int k = 0; k < LOGIT_MAPS; ++k) acc[k] = 0.f;
-    for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+    const bool unsup = ctl->unsupervised != 0;   // QuerySAT(supervised=False), model/query_sat.py:293-309
+    if (unsup)
+        for (int c = cseg[g] + threadIdx.x; c < cseg[g + 1]; c += 256) unsup_clause_loss8(logits, rowptr, c_lit, c, N, acc);
+    for (int v = v0 + threadIdx.x; v < v1 && !unsup; v += 256) {
         const float a = (float)labels[v] * (1.f - tl) + tl * 0.5f;
         const float4 l0 = ld4(logits + (size_t)v * LOGIT_MAPS);
         const float4 l1 = ld4(logits + (size_t)v * LOGIT_MAPS + 4);
@@ -279,10 +283,10 @@ __global__ __launch_bounds__(256) void select_kernel(
     if (threadIdx.x == 0) {
         const float inv = 1.f / (float)(v1 - v0);
         int bi = 0;
-        float bv = red[0][0] * inv;
+        float bv = unsup ? unsup_graph_loss(red[0][0]) : red[0][0] * inv;
         pgl[g * LOGIT_MAPS] = bv;
         for (int k = 1; k < LOGIT_MAPS; ++k) {
-            const float x = red[0][k] * inv;
+            const float x = unsup ? unsup_graph_loss(red[0][k]) : red[0][k] * inv;
             pgl[g * LOGIT_MAPS + k] = x;
             if (x < bv) { bv = x; bi = k; }   // first minimum wins, as TF's CPU ArgMin
         }
@@ -304,7 +308,7 @@ void launch_select(const dsat_graph* g, const float* logits, const int32_t* labe
                    hipStream_t st) {
     if (g->G == 0) return;
     hipLaunchKernelGGL(select_kernel, dim3(g->G), dim3(256), 0, st, g->var_seg, logits, labels, ctl, pgl,
-                       best, out_logits, assign, graph_unsat);
+                       best, out_logits, assign, graph_unsat, g->cl_seg, g->c_rowptr, g->c_lit, g->N);
 }
 
 // ---------------------------------------------------------------- SAT check

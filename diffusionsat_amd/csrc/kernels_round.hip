@@ -1987,7 +1987,10 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
     float acc[LOGIT_MAPS];
 #pragma unroll
     for (int k = 0; k < LOGIT_MAPS; ++k) acc[k] = 0.f;
-    for (int v = v0 + tid; v < v1; v += NTH) {
+    const bool unsup = ctl->unsupervised != 0;
+    if (unsup)   // supervised=False: the graph's own clause loss per logit map (every part recomputes all of it)
+        for (int c = cseg[g] + tid; c < cseg[g + 1]; c += NTH) unsup_clause_loss8(logits, rowptr, c_lit, c, N, acc);
+    for (int v = v0 + tid; v < v1 && !unsup; v += NTH) {
         int label;
         if (ctl->inj_labels != nullptr) {
             label = ctl->inj_labels[ctl->labels_step_stride * ctl->step + logical_var(ctl, v)];
@@ -2020,10 +2023,10 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
     if (tid == 0) {
         const float inv = 1.f / (float)(v1 - v0);
         int bi = 0;
-        float bv = red[0][0] * inv;
+        float bv = unsup ? unsup_graph_loss(red[0][0]) : red[0][0] * inv;
         if (part == 0) pgl[g * LOGIT_MAPS] = bv;
         for (int k = 1; k < LOGIT_MAPS; ++k) {
-            const float x = red[0][k] * inv;
+            const float x = unsup ? unsup_graph_loss(red[0][k]) : red[0][k] * inv;
             if (part == 0) pgl[g * LOGIT_MAPS + k] = x;
             if (x < bv) { bv = x; bi = k; }   // first minimum wins, as TF's CPU ArgMin
         }

@@ -280,13 +280,11 @@ class QuerySAT:
                  test_rounds=64, query_maps=128, supervised=True, trial=None, device="cuda:0", seed=0, **kwargs):
         if trial is not None:
             raise NotImplementedError("Optuna trials belong to training (hyperopt.py); not on this path")
-        if not supervised:
-            raise NotImplementedError("supervised=False selects the logit map by the unsupervised clause loss "
-                                      "(model/query_sat.py:293-309); the kernels implement the supervised selection "
-                                      "the released sampler runs (:289-292, :317-320)")
+        if kwargs.pop("use_linear_loss", False):
+            raise NotImplementedError("use_linear_loss (model/query_sat.py:97, :294-304) is off in the reference and not built")
         if not (1 <= feature_maps <= 128 and 1 <= query_maps <= 128):
             raise NotImplementedError("the kernels' rows are 128 floats wide: feature_maps and query_maps must be in 1..128")
-        self.supervised = supervised
+        self.supervised = bool(supervised)
         self.optimizer = optimizer
         self.train_rounds, self.test_rounds = train_rounds, test_rounds
         self.feature_maps, self.query_maps, self.vote_layers = feature_maps, query_maps, vote_layers
@@ -372,8 +370,10 @@ class QuerySAT:
     def _session(self, gi: GraphInputs) -> runtime.Session:
         key = id(gi)
         if key not in self._sessions:
-            self._sessions[key] = (gi, runtime.Session(gi.graph, self.device_weights(),
-                                                       max_rounds=max(self.test_rounds, 1), device=self.device))
+            sess = runtime.Session(gi.graph, self.device_weights(), max_rounds=max(self.test_rounds, 1),
+                                   device=self.device)
+            sess.set_supervised(bool(self.supervised))       # :289-309: which loss picks a graph's logit map
+            self._sessions[key] = (gi, sess)
         return self._sessions[key][1]
 
     # -- the tf.function entry points on the sampling path ---------------------------------

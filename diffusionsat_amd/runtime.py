@@ -401,6 +401,11 @@ class Session:
     def set_graph_replay(self, enable: bool):
         _lib.check(_lib.load().dsat_session_set_graph_replay(self.handle, int(enable)))
 
+    def set_supervised(self, supervised: bool):
+        """``QuerySAT(supervised=...)``: True = logit map by the KL to the labels, False = by the graph's own
+        unsupervised clause loss (model/query_sat.py:289-309; ``dsat_session_set_supervised``)."""
+        _lib.check(_lib.load().dsat_session_set_supervised(self.handle, int(bool(supervised))))
+
     def set_retire(self, enable: bool):
         """Drop solved copies from a batch of identical copies between denoising steps (``dsat_session_set_retire``)."""
         _lib.check(_lib.load().dsat_session_set_retire(self.handle, int(enable)))

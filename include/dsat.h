@@ -133,6 +133,12 @@ void dsat_weights_destroy(dsat_weights* w);
 int dsat_session_create(const dsat_graph* g, const dsat_weights* w, int32_t max_rounds,
                         dsat_session** out);
 void dsat_session_destroy(dsat_session* s);
+/* QuerySAT(..., supervised=...) (model/query_sat.py:86-91).  1 (default, what the released sampler constructs,
+ * satuniformity/DiffusionSampler.py:199-201): a graph's logit map is the one with the smallest normalised
+ * Bernoulli-KL to the step's labels (:289-292, :40-53).  0: the one with the smallest unsupervised clause loss of the
+ * graph's own clauses, sqrt(sum_c softplus_mixed_loss_adj + 1e-6) - sqrt(1e-6) (:293-309 with use_linear_loss = False;
+ * loss/sat.py:92-100); the labels are then unused.  Takes effect from the next step. */
+int dsat_session_set_supervised(dsat_session* s, int32_t supervised);
 /* 1 (default) = replay each denoising step from a captured hipGraph; 0 = eager. */
 int dsat_session_set_graph_replay(dsat_session* s, int32_t enable);
 

@@ -187,6 +187,15 @@ def softplus_loss_adj(q, cl_adj):
     return np.exp(-(cl_adj @ literals))
 
 
+def softplus_mixed_loss_adj(variable_predictions, cl_adj, eps=1e-8):
+    """loss/sat.py:92-100: clauses_val * -(log(1 - clauses_val + eps) - log(1 + eps)) per clause and logit map;
+    every operation in the dtype of the predictions, as the reference's float32 graph does (1 + 1e-8 is 1 there)."""
+    dt = variable_predictions.dtype.type
+    val = softplus_loss_adj(variable_predictions, cl_adj)
+    log_clauses = -(np.log((dt(1) - val) + dt(eps)) - np.log(dt(1) + dt(eps)))
+    return val * log_clauses
+
+
 def is_batch_sat(predictions, cl_adj):
     """utils/sat.py:118-124.  np.round is half-to-even like tf.round."""
     dt = predictions.dtype.type
@@ -240,7 +249,7 @@ def train_loss(labels, logits, t, label_smoothing=0.01):
 # --------------------------------------------------------------------------- model
 
 def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds,
-                   early_exit=True, dt=np.float32, denoised_num=None, trace=False):
+                   early_exit=True, dt=np.float32, denoised_num=None, trace=False, supervised=True):
     """``QuerySAT.call`` + ``QuerySAT.loop`` at inference.
 
     model/query_sat.py:133-184 (state init, labels) and :186-373 (prologue and
@@ -339,8 +348,13 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
         variables = new_variables + f(0.1) * variables              # :280
 
         logits = mlp(variables, w["variables_output"])              # :283
-        per_var_loss = train_loss(smoothed, logits, noise_scale)    # :291
-        per_graph_loss = vg_norm @ per_var_loss                     # :292   [G, 8]
+        if supervised:
+            per_var_loss = train_loss(smoothed, logits, noise_scale)    # :291
+            per_graph_loss = vg_norm @ per_var_loss                     # :292   [G, 8]
+        else:   # QuerySAT(supervised=False), use_linear_loss = False (:97): :306-309
+            per_clause_loss = softplus_mixed_loss_adj(logits, cl_adj)   # [C, 8]
+            per_graph_loss = cg @ per_clause_loss                       # the un-normalised clauses_graph: a sum
+            per_graph_loss = np.sqrt(per_graph_loss + f(1e-6)) - np.sqrt(f(1e-6))
         best_map = np.argmin(per_graph_loss, axis=-1)               # :317 (first minimum on ties)
         best_per_var = best_map[vmask]                               # :318-320
         out_logits = logits[np.arange(n_vars), best_per_var].reshape(n_vars, 1)  # :328-329
@@ -368,12 +382,12 @@ def query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds
 
 
 def diffusion_step(weights, data, noise_scale, noisy_num, normal, labels, rounds=32,
-                   early_exit=True, dt=np.float32, trace=False, denoised_num=None):
+                   early_exit=True, dt=np.float32, trace=False, denoised_num=None, supervised=True):
     """model/query_sat.py:467-481 (``QuerySAT.diffusion_step``): labels=None at the
     call site means random labels (:145); they are the explicit ``labels`` here."""
     # denoised_num [N,1]: QuerySAT.diffusion_step_self (model/query_sat.py:483-498)
     return query_sat_loop(weights, data, noise_scale, noisy_num, normal, labels, rounds,
-                          early_exit=early_exit, dt=dt, trace=trace, denoised_num=denoised_num)
+                          early_exit=early_exit, dt=dt, trace=trace, denoised_num=denoised_num, supervised=supervised)
 
 
 # --------------------------------------------------------------------------- sampler

@@ -215,10 +215,13 @@ def test_sparse_tensors_follow_sat_specifics():
         sparse.as_coo(np.zeros((2, 2)))
 
 
-def test_supervised_false_and_foreign_layer_options_raise():
+def test_foreign_model_and_layer_options_raise():
     from diffusionsat_amd.query_sat import MLP, PairNorm, QuerySAT
-    with pytest.raises(NotImplementedError, match="supervised"):
-        QuerySAT(optimizer=None, supervised=False)
+    with pytest.raises(NotImplementedError, match="use_linear_loss"):
+        QuerySAT(optimizer=None, supervised=False, use_linear_loss=True)
+    with pytest.raises(NotImplementedError, match="Optuna"):
+        QuerySAT(optimizer=None, trial=object())
+    assert QuerySAT(optimizer=None, supervised=False).supervised is False        # built: tests/test_gpu_boundary.py
     with pytest.raises(NotImplementedError):
         MLP(3, 16, 4, out_activation=lambda x: x)
     m = MLP(3, 16, 4, name="m")

@@ -159,7 +159,65 @@ def test_pair_norm_has_the_reference_signature():
         assert np.abs(y - c / np.sqrt((c ** 2).mean(axis=1, keepdims=True) + 1e-3)).max() < 2e-5
 
 
-def test_unsupervised_selection_is_refused():
-    from diffusionsat_amd.query_sat import QuerySAT
-    with pytest.raises(NotImplementedError, match="supervised"):
-        QuerySAT(optimizer=None, supervised=False)
+@pytest.mark.parametrize("kind", ["3sat", "ragged", "medium"])
+def test_unsupervised_selection_matches_oracle(kind, monkeypatch):
+    """QuerySAT(supervised=False): the logit map of a graph is picked by the unsupervised clause loss of its own
+    clauses, sqrt(sum softplus_mixed_loss_adj + 1e-6) - sqrt(1e-6) (model/query_sat.py:293-309, loss/sat.py:92-100),
+    on the fused kernels and on the per-layer path; the labels play no part."""
+    from diffusionsat_amd import runtime as rt
+    from diffusionsat_amd.query_sat import GraphInputs, QuerySAT
+    insts, batch, data = make_all(kind)
+    ws = oracle_weights(6)
+    rounds = 6
+    d = draws(batch.n_vars, rounds, seed=8)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.4), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32, trace=("per_graph_loss", "best_map", "logits"), supervised=False)
+    sup = O.diffusion_step(ws, data, np.float32(0.4), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32, trace=("per_graph_loss",), supervised=True)
+    ssrt = np.sort(sup["trace"]["per_graph_loss"][-1], axis=1)
+    sclear = (ssrt[:, 1] - ssrt[:, 0]) > 1e-3
+    pgl = ref["trace"]["per_graph_loss"][-1]
+    srt = np.sort(pgl, axis=1)
+    clear = (srt[:, 1] - srt[:, 0]) > 1e-4 * np.maximum(1.0, srt[:, 0])
+    assert clear.any()
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DSAT_FUSED", fused)
+        g, w = rt.Graph(batch), rt.Weights(ws)
+        s = rt.Session(g, w, max_rounds=rounds)
+        s.set_supervised(False)
+        args = (0.4, _dev(noisy), _dev(d["normal"]))
+        out = s.diffusion_step(*args, _dev(d["labels"]), rounds=rounds, early_exit=False, want_logits=True)
+        best = out["best_map"].cpu().numpy()
+        assert np.array_equal(best[clear], ref["best_map"][clear]), fused
+        assert np.abs(out["logits"].cpu().numpy() - ref["logits"]).max() < 2e-4
+        vclear = clear[data["variables_mask"]]
+        assert np.abs(out["prediction"].cpu().numpy() - ref["prediction"])[vclear].max() < 2e-4
+        flipped = s.diffusion_step(*args, _dev(1 - d["labels"]), rounds=rounds, early_exit=False)     # labels are unused
+        assert torch.equal(flipped["best_map"], out["best_map"]) and torch.equal(flipped["prediction"], out["prediction"])
+        s.set_supervised(True)                                        # and back: the supervised pick again
+        back = s.diffusion_step(*args, _dev(d["labels"]), rounds=rounds, early_exit=False)
+        assert np.array_equal(back["best_map"].cpu().numpy()[sclear], sup["best_map"][sclear])
+    monkeypatch.delenv("DSAT_FUSED")
+    assert not np.array_equal(ref["best_map"], sup["best_map"])      # the two rules really pick differently
+    # through the facade
+    model = QuerySAT(optimizer=None, test_rounds=rounds, supervised=False)
+    model.set_weights(ws)
+    o = model.diffusion_step(GraphInputs(batch), None, None, None, 0.4, _dev(noisy), normal=_dev(d["normal"]),
+                             labels=_dev(d["labels"]), early_exit=False)
+    vclear = clear[data["variables_mask"]]
+    assert np.abs(o["prediction"].cpu().numpy() - ref["prediction"])[vclear].max() < 2e-4
+
+
+def test_unsupervised_early_exit_on_a_tautology():
+    """is_batch_sat still ends the loop (model/query_sat.py:330-338) when the unsupervised rule picks the map."""
+    from diffusionsat_amd import runtime as rt
+    from diffusionsat_amd.batch import make_batch
+    batch = make_batch([(6, [[1, -1, 2], [3, -3], [4, 5, -4], [6, -6, 1]])] * 3)
+    s = rt.Session(rt.Graph(batch), rt.Weights(oracle_weights(1)), max_rounds=5)
+    s.set_supervised(False)
+    noisy = _dev(np.tile(np.array([[1, 0]], np.float32), (batch.n_vars, 1)))
+    out = s.diffusion_step(0.5, noisy, rounds=5, early_exit=True, seed=3, step_index=1)
+    assert int(out["steps_taken"].item()) == 0
+    smp = s.sample(3, 5, seed=2, early_exit=True)
+    assert smp["solved_fraction"] == 1.0
