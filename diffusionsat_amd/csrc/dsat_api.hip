@@ -772,6 +772,8 @@ struct dsat_session {
     float *x0b = nullptr, *x1b = nullptr;   // second x buffers (the survivors move between steps)
     int32_t* n_act_host = nullptr;          // pinned
     int no_cn = 0;                 // DSAT_NO_CN (ablation): P2 finishes the clause PairNorm itself
+    int cn_in_p3 = 1;              // role C rides in P3's grid when its last wave of tiles leaves CUs idle (DSAT_CN_P3=0: only in P1's)
+    double cn_frac = 1.0;          // ... on grids of several waves: this share of the clause rows (DSAT_CN_P3_FRAC; 0.5 / 0.75 measured: less gain)
     char* slab = nullptr;
     size_t slab_bytes = 0;
     // state + intermediates (see DESIGN.md "HBM layout")
@@ -1342,6 +1344,8 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
     }
     s->g = g; s->w = w; s->max_rounds = max_rounds;
     s->no_cn = getenv("DSAT_NO_CN") != nullptr;
+    { const char* e = getenv("DSAT_CN_P3"); s->cn_in_p3 = e == nullptr ? 1 : atoi(e); }
+    { const char* e = getenv("DSAT_CN_P3_FRAC"); if (e != nullptr) s->cn_frac = std::min(1.0, std::max(0.0, atof(e))); }
     memset(&s->tap, 0, sizeof(s->tap));
     {   // tile sizes are fixed before the workspace is carved: P1/P3 16 rows, P2 16*p2_rb rows
         const auto& cl = w->mlp[DSAT_MLP_CLAUSE];
@@ -1991,6 +1995,8 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
     a1.check_done = a2.check_done = a3.check_done = early_exit;
     a1.trace_logits = trace_logits;
     int pb_first = 0, pb_blocks = -1;
+    int cn3_prev = 0;   // role-C blocks the previous round's P3 carried: the clause state is already normalised ...
+    int cn3_rows = 0;   // ... for rows below this (0: all of them)
     // the non-state columns of v1 (normal draw, noisy_num, noise_scale, denoised) of all rounds
     L.run(KC_MISC, [&] { launch_aux(s->aux, actN, rounds, s->in_noisy, s->ctl, st); });   // :214-219, :239
     for (int r = 0; r <= rounds; ++r) {
@@ -2015,7 +2021,7 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         }
         a1.a1_split = s->p1_a1s && !s->p1_a2 && !a1.tail && a1.pair_first == 0 && a1.pair_blocks == (actN + 63) / 64;
         const int free_cus = s->n_cus - (s->p1_a2 ? a1.a2_tiles : vtiles) - a1.pair_blocks;
-        const int cn = (r > 0 && r < rounds && actC > 0 && free_cus >= 8 && !s->no_cn) ? free_cus : 0;
+        const int cn = (r > 0 && r < rounds && actC > 0 && free_cus >= 8 && !s->no_cn && cn3_prev == 0) ? free_cus : 0;
         a1.cn_blocks = cn;
         float* vbuf[2] = {s->V, s->Vlog};   // carried state, double-buffered by round (Vlog is free on this path)
         a1.V_in = vbuf[(r & 1) ^ 1];
@@ -2035,7 +2041,8 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         }
         a2.round = r;
         a2.s_enable = early_exit && r > 0;   // G extra blocks: select/SAT of round r-1
-        a2.cs_ready = cn > 0;
+        a2.cs_ready = cn > 0 || cn3_prev > 0;
+        a2.cs_ready_rows = cn3_prev > 0 ? cn3_rows : 0;
         {
             a2.psum_c_wr = s->psum_c + (r & 1) * half;
             a2.psum_c_rd = s->psum_c + ((r + 1) & 1) * half;
@@ -2082,6 +2089,38 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
                 note(launch_heavy_gather(reinterpret_cast<const int2*>(s->pieces), s->n_pieces, s->g->l_clause,
                                          s->closs4, s->vla, s->g->C, s->hpart, done_flag, st));
             });
+        {   // Role C in P3: the clause PairNorm of this round, which P2 of the next round would otherwise do inside every
+            // tile (12.7 k cycles per 64-row tile at config 3, where P1 has no idle CU for it) or P1's role C on its few
+            // idle CUs.  The CUs P3's LAST wave of tiles leaves idle (all but the tiles' own when there is one wave) take
+            // it, as blocks behind the tiles.  One wave (config 2): everything (L2-resident, ~60 cycles per row).  Several
+            // waves: the rows stream from HBM then, 1.5 KB per row, and the blocks outlast the last wave's tiles (config 3:
+            // P3 130 -> 147 us) -- but P2 loses more than that (247 -> 220 us): 56.7 -> 57.9 steps/s, config 5 95.0 -> 97.4.
+            // cn_frac < 1 hands over only the first share of the rows (whole P2 tiles; the rest is normalised inside P2's
+            // tiles as before): 0.5 and 0.75 gave less (57.7 / 57.8, 95.2 / 95.2), so the default is all rows.
+            // (Role-C rows BETWEEN the tile rows, DSAT_CN_P3=2, were measured and lost: a block holds a whole CU while it
+            // waits for memory -- config 3: P3 227 us against 147 us with the blocks behind the tiles.)
+            const int p3tiles = (actN + s->p3_bm - 1) / s->p3_bm;
+            const bool host_c = r + 1 < rounds && actC > 0 && !s->no_cn && s->cn_in_p3 > 0;
+            const int rem = p3tiles % s->n_cus;
+            const int idle3 = p3tiles < s->n_cus ? s->n_cus - p3tiles : (rem == 0 ? 0 : s->n_cus - rem);
+            a3.cn_blocks = 0;
+            a3.cn_period = 0;
+            a3.cn_rows = 0;
+            if (host_c && s->cn_in_p3 == 2 && p3tiles >= s->n_cus && s->stamps == nullptr) {   // experiment: interleaved rows
+                const int nc = std::max(8, std::min(p3tiles, actC / 64));
+                a3.cn_blocks = nc;
+                a3.cn_period = std::max(1, ((p3tiles + 7) / 8) / ((nc + 7) / 8));
+            } else if (host_c && idle3 >= 8) {
+                const int rows = p3tiles < s->n_cus ? actC : std::min(actC, (int)((double)actC * s->cn_frac) / 64 * 64);
+                if (rows > 0 && (int64_t)rows <= (int64_t)idle3 * 1200) {
+                    a3.cn_blocks = idle3;
+                    a3.cn_rows = rows < actC ? rows : 0;
+                }
+            }
+            a3.psum_c_rd = a2.psum_c_wr;    // the column sums P2 of this round wrote (level-2 sums: segsum2 above)
+            cn3_prev = a3.cn_blocks;
+            cn3_rows = a3.cn_rows;
+        }
         L.run(KC_ROUND_P3, [&] { note(launch_round_p3(a3, st)); });
         if (s->n_vchunks > 0)
             L.run(KC_SEGSUM2, [&] {

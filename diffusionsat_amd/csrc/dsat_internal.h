@@ -272,8 +272,16 @@ struct RoundArgs {
     int pair_first;          // first 64-row group role B covers (rows below it: the pair runs in the 16-row tile)
     int b_off_x, b_off_vlog, b_off_a, b_off_b, b_off_mean, b_ld_a, b_ld_b;   // LDS plan of a role-B workgroup
     int s_enable;          // P2 only: append G blocks running select/SAT of round-1
-    int cn_blocks;         // P1 only: extra blocks that finish the clause PairNorm of round-1 (R10)
-                           //          on CUs the variable tiles leave idle; 0 = P2 does it itself
+    int cn_blocks;         // P1: extra blocks that finish the clause PairNorm of round-1 (R10)
+                           //     on CUs the variable tiles leave idle; 0 = P2 does it itself.
+                           // P3: the same for THIS round's clause state (round 3), behind the tiles (cn_period = 0) or,
+                           //     on grids of several waves of workgroups, as whole rows of 8 blocks after every
+                           //     cn_period rows of 8 tiles, so that their row streaming runs beside the tiles' MFMA work
+    int cn_period;         // P3: see cn_blocks
+    int cn_rows;           // role C covers clause rows [0, cn_rows) (a multiple of P2's tile height unless it is all of them)
+    int cs_ready_rows;     // P2: clause rows below this were normalised by a role C before this launch (replaces the
+                           //     all-or-nothing cs_ready for P3-hosted role C on large batches)
+    int p3_tiles;          // P3: variable tiles of the launch (the grid also holds the role-C blocks)
     int cs_ready;          // P2 only: clause_state was already normalised by P1's extra blocks
     int round;             // message-passing round this launch belongs to
     int check_done;        // early exit armed: skip when ctl->done

@@ -133,6 +133,22 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+// What a block of P3's grid does: tile block `idx` (to be mapped by xcd_tile; >= p3_tiles: nothing), or role-C block
+// `idx` (clause_norm_block; < 0: nothing).  The grid is rows of 8 blocks (one per XCD under round-robin placement), so
+// a tile keeps the XCD of its index whether or not role-C rows sit between the tile rows.
+struct P3Slot { bool is_c; int idx; };
+__device__ __forceinline__ P3Slot p3_slot(const RoundArgs& a) {
+    const int b = (int)blockIdx.x;
+    if (a.cn_period <= 0) return b >= a.p3_tiles ? P3Slot{true, b - a.p3_tiles} : P3Slot{false, b};
+    const int j = b >> 3, x = b & 7, cyc = a.cn_period + 1, c_rows = (a.cn_blocks + 7) >> 3;
+    const int i = j / cyc;
+    if (j - i * cyc == a.cn_period && i < c_rows) {
+        const int c = i * 8 + x;
+        return P3Slot{true, c < a.cn_blocks ? c : -1};
+    }
+    return P3Slot{false, (j - min(c_rows, i)) * 8 + x};
+}
+
 __device__ __forceinline__ TileMetaDev load_meta(const int32_t* meta, int tile) {
     TileMetaDev m;
     const int4* p = reinterpret_cast<const int4*>(meta + (size_t)tile * TILE_META_INTS);
@@ -452,7 +468,7 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
 // R10 for a contiguous range of clause rows (one of `nb` extra workgroups of P1): same arithmetic
 // as pairnorm_tile, streamed; clause_state is updated in place for P2 to load.
 __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int nb, float* sMean, int tid) {
-    const int C = a.C;
+    const int C = a.cn_rows > 0 ? min(a.cn_rows, a.C) : a.C;   // its share of the rows role C covers in this launch
     const int per = (C + nb - 1) / nb;
     const int lo0 = b * per, hi0 = min(lo0 + per, C);
     if (lo0 >= hi0) return;
@@ -984,7 +1000,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
         staged = stage_csr(a.cg_rowptr, a.cg_lit, tile_lo, tile_hi - tile_lo, tm.e_base0, tm.e_end0, sPtr, sIdx,
                            BM * a.ld_a - (BM + 8), tid);
     }
-    if (a.cs_ready && a.round > 0) {   // R10 was finished by P1's extra blocks: just load the rows
+    if (a.cs_ready && a.round > 0 && (a.cs_ready_rows <= 0 || tile_hi <= a.cs_ready_rows)) {   // R10 was finished by a role C: just load the rows
         const int sub = tid & 31, hw = tid >> 5;
 #pragma unroll
         for (int kq = 0; kq < ROWS; ++kq) {
@@ -1188,7 +1204,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
     const int tile_lo = tile * BM;
     const int tile_hi = min(tile_lo + BM, C);
     // ... and with the carried clause state of the tile's rows (finished by P1's extra blocks)
-    const bool rows_ready = !extra && a.cs_ready && a.round > 0;
+    const bool rows_ready = !extra && a.cs_ready && a.round > 0 && (a.cs_ready_rows <= 0 || tile_hi <= a.cs_ready_rows);
     float4 srow[ROWS];
 #pragma unroll
     for (int kq = 0; kq < ROWS; ++kq) {
@@ -1450,12 +1466,18 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3_kern
     constexpr int GJ = DSAT_GJ3;                // clause rows in flight per literal (x PASSES x 2 arrays)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.N, NL = a.NL;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const P3Slot slot = p3_slot(a);                    // a tile, or role C (see round_p3s_kernel)
+    const bool roleC = slot.is_c || slot.idx >= a.p3_tiles;
+    const int tile = roleC ? 0 : xcd_tile(slot.idx, a.p3_tiles);
     const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
     const TileMetaDev tm = load_meta(a.vmeta, tile);
     ListBlock lb;                                       // ... and with the tile's literal -> clause lists
-    list_block_fetch(lb, a.vlist, a.vlist_stride, tile, tid);
+    list_block_fetch(lb, roleC ? nullptr : a.vlist, a.vlist_stride, tile, tid);
     if (both_arrived(done, tm) != 0) return;
+    if (roleC) {
+        if (slot.is_c && slot.idx >= 0) clause_norm_block(a, slot.idx, a.cn_blocks, smem, tid);
+        return;
+    }
     if (a.sel_zero && blockIdx.x == 0)   // multi-part select adds its counts up: start the next one from zero
         for (int g = tid; g < a.G; g += NT) a.graph_unsat[g] = 0;
     const int tile_lo = tile * BM;
@@ -1656,13 +1678,17 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
     constexpr int GJ = BM > 16 ? (DSAT_GJ3 + 1) / 2 : DSAT_GJ3;   // clause rows in flight per literal (x PASSES x 2 arrays)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.N, NL = a.NL;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    // role C: the blocks behind the tiles finish the clause PairNorm (R10) of THIS round for P2 of the next one, on the
+    // CUs the last wave of tiles leaves idle (dsat_api.hip, cn3)
+    const P3Slot slot = p3_slot(a);
+    const bool roleC = slot.is_c || slot.idx >= a.p3_tiles;
+    const int tile = roleC ? 0 : xcd_tile(slot.idx, a.p3_tiles);
     const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
     const TileMetaDev tm = load_meta(a.vmeta, tile);
     ListBlock lb;                                       // ... and with the tile's literal -> clause lists
-    list_block_fetch(lb, a.vlist, a.vlist_stride, tile, tid);
+    list_block_fetch(lb, roleC ? nullptr : a.vlist, a.vlist_stride, tile, tid);
     const int tile_lo = tile * BM;
-    const int tile_hi = min(tile_lo + BM, N);
+    const int tile_hi = roleC ? tile_lo : min(tile_lo + BM, N);   // (role C: none of the row prefetches below)
     // ... and with the rows that do not depend on the lists: q (half 0) and the carried state (half 1)
     float4 rowv[PASSES], qrow[PASSES];
     float wdeg[PASSES], wv[PASSES];
@@ -1674,7 +1700,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
         qrow[u] = rowv[u];
         wdeg[u] = 0.f; wv[u] = 0.f;
         hv[u] = make_int2(-1, 0);
-        if (v < N) {
+        if (v < tile_hi) {
             if (a.l_hv != nullptr) hv[u] = a.l_hv[v + half_ * NL];
             qrow[u] = ld4(a.q + (size_t)v * F + sub_ * 4);
             if (half_ == 1) rowv[u] = ld4(a.V + (size_t)v * F + sub_ * 4);
@@ -1689,10 +1715,14 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
     for (int rb = 0; rb < BM / 16; ++rb) {
         upd0[rb] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int n = tile_lo + rb * 16 + (lane & 15);
-        if (a.upd_part != nullptr && wave < a.sp_nt[0] && n < N)
+        if (a.upd_part != nullptr && wave < a.sp_nt[0] && n < tile_hi)
             upd0[rb] = ld4(a.upd_part + (size_t)n * a.upd_ld + wave * 16 + 4 * (lane >> 4));
     }
     if (both_arrived(done, tm) != 0) return;
+    if (roleC) {
+        if (slot.is_c && slot.idx >= 0) clause_norm_block(a, slot.idx, a.cn_blocks, smem, tid);
+        return;
+    }
     if (a.sel_zero && blockIdx.x == 0)   // multi-part select adds its counts up: start the next one from zero
         for (int g = tid; g < a.G; g += NT) a.graph_unsat[g] = 0;
     unsigned char* sbytes = reinterpret_cast<unsigned char*>(smem);
@@ -2123,16 +2153,20 @@ hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t launch_round_p3(const RoundArgs& a, hipStream_t st) {
-    const int tiles = (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR;
+hipError_t launch_round_p3(const RoundArgs& a0, hipStream_t st) {
+    RoundArgs a = a0;
+    const int bm = (a.sp_ws[0] != nullptr && a.p3_bm == 32) ? 32 : ROUND_BM_VAR;
+    a.p3_tiles = (a.N + bm - 1) / bm;
+    // tiles, then the role-C blocks; or, interleaved, rows of 8: cn_period tile rows, one role-C row, ...
+    const int grid = a.cn_period > 0 ? 8 * ((a.p3_tiles + 7) / 8 + (a.cn_blocks + 7) / 8) : a.p3_tiles + a.cn_blocks;
 #if DSAT_ROUND_NWAVES == 16
     if (a.sp_ws[0] != nullptr) {
-        if (a.p3_bm == 32) hipLaunchKernelGGL(round_p3s_kernel<32>, dim3((a.N + 31) / 32), dim3(NT), 0, st, a);
-        else hipLaunchKernelGGL(round_p3s_kernel<16>, dim3(tiles), dim3(NT), 0, st, a);
+        if (a.p3_bm == 32) hipLaunchKernelGGL(round_p3s_kernel<32>, dim3(grid), dim3(NT), 0, st, a);
+        else hipLaunchKernelGGL(round_p3s_kernel<16>, dim3(grid), dim3(NT), 0, st, a);
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL(round_p3_kernel, dim3(tiles), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL(round_p3_kernel, dim3(grid), dim3(NT), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_segsum2(const int2* chunks, int n_chunks, const float* psum, float* psum2, const int* done,
