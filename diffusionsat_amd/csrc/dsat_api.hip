@@ -1312,6 +1312,7 @@ static bool plan_round(dsat_session* s) {
                 s->p3_part = s->p2_split && !(ep != nullptr && ep[0] == '0') && F % 32 == 0 &&
                              s->hid_ld[DSAT_MLP_UPDATE_GATE] >= 16 * r.sp_nt[0] && r.sp_nt[0] <= ROUND_NWAVES &&
                              3 * 64 * (F + 16) * 2 <= LDS * 4;
+                if (s->p3_part && ep != nullptr && ep[0] == '2') s->p3_part = 2;   // also in the last wave of a multi-wave P2
             }
         }
         if (s->p3_bm == 32 && !s->p3_split) ok = false;   // the tables were built for 32-row producer tiles
@@ -1965,7 +1966,12 @@ static int role_d_blocks(const dsat_session* s, int actN, int actC, bool sel_on,
     *dsel = 0;
     if (!s->p3_part || s->prefer_tp || s->p2_rb != 4) return 0;
     const int p2_blocks = (actC + 63) / 64 + (sel_on ? (sel_lead > 0 ? sel_lead : n_sel) : 0);
-    const int nd = (actN + 63) / 64, free_cus = s->n_cus - p2_blocks;
+    // CUs without a clause tile: all but the tiles' own in a single wave of workgroups, those of the LAST wave otherwise
+    // (the role-D blocks are the last of the grid, so that is where they land; DSAT_P3_PART=2 to allow it)
+    const int rem2 = p2_blocks % s->n_cus;
+    const int nd = (actN + 63) / 64;
+    const int free_cus = p2_blocks < s->n_cus ? s->n_cus - p2_blocks
+                                              : (s->p3_part >= 2 && rem2 != 0 ? s->n_cus - rem2 : 0);
     const int sel_workers = sel_on && sel_lead == 0 ? n_sel : 0;
     const int extra_blocks = std::min(std::max(nd - sel_workers, 1), std::max(free_cus, 0));
     if (free_cus < 8 || nd > 3 * extra_blocks + sel_workers) return 0;

@@ -1475,7 +1475,11 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3_kern
     list_block_fetch(lb, roleC ? nullptr : a.vlist, a.vlist_stride, tile, tid);
     if (both_arrived(done, tm) != 0) return;
     if (roleC) {
+        DSAT_STAMP_RT_BEGIN(a);
+        DSAT_STAMP(a, 0);
         if (slot.is_c && slot.idx >= 0) clause_norm_block(a, slot.idx, a.cn_blocks, smem, tid);
+        DSAT_STAMP(a, 4);
+        DSAT_STAMP_RT_END(a);
         return;
     }
     if (a.sel_zero && blockIdx.x == 0)   // multi-part select adds its counts up: start the next one from zero
@@ -1720,7 +1724,11 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
     }
     if (both_arrived(done, tm) != 0) return;
     if (roleC) {
+        DSAT_STAMP_RT_BEGIN(a);
+        DSAT_STAMP(a, 0);
         if (slot.is_c && slot.idx >= 0) clause_norm_block(a, slot.idx, a.cn_blocks, smem, tid);
+        DSAT_STAMP(a, 4);
+        DSAT_STAMP_RT_END(a);
         return;
     }
     if (a.sel_zero && blockIdx.x == 0)   // multi-part select adds its counts up: start the next one from zero

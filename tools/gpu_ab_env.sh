@@ -1,17 +1,17 @@
 #!/bin/bash
-# A/B of environment switches on the config-2 bench, same box:  gpu_ab_env.sh <outdir> "<VAR=val ...>" ...
-O=gpurun_out/${1:-abenv}; shift
-mkdir -p $O
-i=0
-run() { name=$1; shift; env "$@" python bench.py --repeats 3 --no-cpu-baseline --no-secondary > $O/$name.json 2> $O/$name.err; python - <<PY
-import json
-try:
-    d=json.load(open("$O/$name.json"))
-    print("%-28s"%"$*", round(d["value"],1), d["repeats"]["ms_per_step_all"], {k:round(v["avg_launch_us"],1) for k,v in d["roofline_kernels"].items()})
-except Exception as e:
-    print("$name FAILED", e); print(open("$O/$name.err").read()[-600:])
+# A/B of environment switches on bench.py: tools/gpu_ab_env.sh OUTDIR "CONFIGS" "NAME=ENV ..." (ENV: comma-separated K=V, or "-")
+O=gpurun_out/$1; mkdir -p $O
+for c in $2; do for spec in $3; do
+  n=${spec%%=*}; e=${spec#*=}; [ "$e" = "-" ] && e=""
+  env ${e//,/ } python bench.py --config $c --no-cpu-baseline --no-secondary > $O/cfg${c}_$n.json 2>&1
+done; done
+python - "$O" <<'PY'
+import glob, json, os, sys
+for f in sorted(glob.glob(os.path.join(sys.argv[1], "cfg*.json"))):
+    t = open(f).read()
+    try:
+        b = json.loads(t[t.index('{"metric"'):].splitlines()[0])
+        print(os.path.basename(f), round(b["value"], 2), {k: round(x["avg_launch_us"], 1) for k, x in b.get("roofline_kernels", {}).items()})
+    except Exception as ex:
+        print(os.path.basename(f), "FAILED", t[-300:])
 PY
-}
-run base DSAT_NOP=1
-for v in "$@"; do i=$((i+1)); run v$i $v; done
-run base2 DSAT_NOP=1

@@ -61,7 +61,7 @@ def collect(config, rounds):
     out = {"round_p1": st[0, :tiles[0]], "round_p2": st[1, :tiles[1]], "round_p3": st[2, :tiles[2]]}
     # the other workgroups of the same grids (role B / clause-norm blocks of P1, select/SAT blocks of P2):
     # whatever follows the tiles and carries stamps
-    for name, k in (("round_p1_extra", 0), ("round_p2_extra", 1)):
+    for name, k in (("round_p1_extra", 0), ("round_p2_extra", 1), ("round_p3_extra", 2)):
         rest = st[k, tiles[k]:]
         out[name] = rest[rest[:, 7] > 0]
     return out, {"config": config, "rounds": rounds, "n_vars": batch.n_vars, "n_clauses": batch.n_clauses,
@@ -105,7 +105,8 @@ def table(stamps, meta):
         out["kernels"][k] = kk
     for k, what in (("round_p1_extra", "P1 role B (64-row pair: pairnorm | out chain | query chain) and role C "
                                        "(clause-norm) workgroups"),
-                    ("round_p2_extra", "P2 select/SAT workgroups")):
+                    ("round_p2_extra", "P2 select/SAT workgroups"),
+                    ("round_p3_extra", "P3 role C workgroups (clause PairNorm of this round, on the CUs the tiles leave idle)")):
         if k in stamps and len(stamps[k]):
             t = stamps[k].astype(np.float64)
             tot = t[:, 4] - t[:, 0]
