@@ -824,6 +824,12 @@ struct dsat_session {
     int p3_part = 0;        // P2's role D forms update_gate's `variables` partial product for P3 (when CUs are free)
     int p1_a1s = 0;         // role A's 16-row tiles run lit_mlp as split products when role B covers every row (role_a1s)
     int p1_a2_env = -1;     // DSAT_P1_A2: 0 never, 1 always, -1 (unset) by batch size / dsat_session_set_throughput
+    // 32-row A tiles can run the output / query pair themselves on large grids (role_a2, pair_here; DSAT_P1_A2_PAIR=1).  Off by
+    // default: measured at config 3 (tools/stamps_a2.py) the pair costs a 32-row tile 28 k cycles (out chain 8.7 k, query
+    // chain 19 k, PairNorm planes 1.2 k) -- two tiles' worth is what the role-B workgroup they replace costs (58 k), so no
+    // CU-cycles are saved, and the list schedule's picks were slower (P1 184 -> 207 us) or equal.
+    int a2_pair_here = 0;
+    double a2_cost[3] = {102.0, 74.0, 58.0};   // plan_pair_blocks: A32 tile with the pair, without, a role-B workgroup (k cycles, config 3)
     int pair_blocks = 0;
     // select/SAT workgroups {graph, part, parts, 0}
     std::vector<int32_t> h_sel_tab;
@@ -1346,6 +1352,9 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
     s->g = g; s->w = w; s->max_rounds = max_rounds;
     s->no_cn = getenv("DSAT_NO_CN") != nullptr;
     { const char* e = getenv("DSAT_CN_P3"); s->cn_in_p3 = e == nullptr ? 1 : atoi(e); }
+    { const char* e = getenv("DSAT_P1_A2_PAIR"); s->a2_pair_here = e != nullptr && e[0] == '1'; }
+    { const char* e = getenv("DSAT_P1_A2_COST");     // "with,without,b" in k cycles (planning experiments)
+      if (e != nullptr) sscanf(e, "%lf,%lf,%lf", &s->a2_cost[0], &s->a2_cost[1], &s->a2_cost[2]); }
     { const char* e = getenv("DSAT_CN_P3_FRAC"); if (e != nullptr) s->cn_frac = std::min(1.0, std::max(0.0, atof(e))); }
     memset(&s->tap, 0, sizeof(s->tap));
     {   // tile sizes are fixed before the workspace is carved: P1/P3 16 rows, P2 16*p2_rb rows
@@ -1929,8 +1938,12 @@ static void enqueue_step(dsat_session* s, hipStream_t st, int rounds, int early_
 // all groups.  On larger grids a few workgroups too many cost a whole extra tile time at the end (625 + 157
 // workgroups = 3.05 waves), so the candidates are compared by a list-scheduling estimate with the measured
 // relative durations (profiles/r02_stamps_*: A tile without the pair 74, with it 95, role-B workgroup 72).
-static void plan_pair_blocks(int n_cus, int n_active, int* first, int* blocks) {
-    const int vtiles = (n_active + ROUND_BM_VAR - 1) / ROUND_BM_VAR, groups = (n_active + 63) / 64;
+static void plan_pair_blocks(int n_cus, int n_active, int* first, int* blocks, int bm = ROUND_BM_VAR,
+                             double cost_with = 95.0, double cost_without = 74.0, double cost_b = 72.0) {
+    // bm / costs: the A tile's height and the relative durations of an A tile that runs the pair itself, of one that
+    // does not, and of a role-B workgroup (16-row tiles on the fp32 MFMA: profiles/r02_stamps_*; 32-row split tiles,
+    // role_a2: profiles/r03_stamps_cfg3.txt)
+    const int vtiles = (n_active + bm - 1) / bm, groups = (n_active + 63) / 64;
     *first = 0;
     *blocks = groups;
     if (vtiles + groups <= n_cus) return;
@@ -1943,8 +1956,8 @@ static void plan_pair_blocks(int n_cus, int n_active, int* first, int* blocks) {
             cu.back() += d;
             std::push_heap(cu.begin(), cu.end(), std::greater<double>());
         };
-        for (int t = 0; t < vtiles; ++t) put(t * ROUND_BM_VAR < f * 64 ? 95.0 : 74.0);
-        for (int b = 0; b < nb; ++b) put(72.0);
+        for (int t = 0; t < vtiles; ++t) put(t * bm < f * 64 ? cost_with : cost_without);
+        for (int b = 0; b < nb; ++b) put(cost_b);
         return *std::max_element(cu.begin(), cu.end());
     };
     double best = makespan(groups);
@@ -2018,8 +2031,16 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         a1.pair_blocks = 0;
         a1.pair_first = 0;
         a1.a2_tiles = s->p1_a2 ? (actN + 31) / 32 : 0;
-        if (s->p1_a2) {                       // 32-row A tiles: role B covers every group, in the tail launch too
+        if (s->p1_a2) {                       // 32-row A tiles: role B covers every group, in the tail launch too --
             a1.pair_blocks = (actN + 63) / 64;
+            // -- or, on grids of several waves of workgroups, only as many groups as balance the waves: the A tiles of the
+            // first rows then run the pair themselves as split chains (role_a2, pair_here)
+            if (s->a2_pair_here && s->ra1.bo_ws[0] != nullptr && s->ra1.sp_ws[0] != nullptr) {
+                if (r == 0 || pb_blocks < 0)
+                    plan_pair_blocks(s->n_cus, actN, &pb_first, &pb_blocks, 32, s->a2_cost[0], s->a2_cost[1], s->a2_cost[2]);
+                a1.pair_blocks = pb_blocks;
+                a1.pair_first = pb_first;
+            }
         } else if (!a1.tail && s->pair_blocks != 0) {
             if (r == 0 || pb_blocks < 0) plan_pair_blocks(s->n_cus, actN, &pb_first, &pb_blocks);
             a1.pair_blocks = pb_blocks;

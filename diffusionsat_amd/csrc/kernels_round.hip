@@ -546,7 +546,12 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
 // LDS: h1 [3][32][528] (first the fp32 PairNorm rows) + max(v1 planes [3][32][176], h2 half [3][32][272]) = 150 KB.
 // 66 k cycles per 32 rows (tools/lit32_probe.hip) against 68 k per 16 rows on the fp32 MFMA.
 #if DSAT_ROUND_NWAVES == 16
-__device__ __forceinline__ void role_a2(const RoundArgs& a, int tile, const TileMetaDev& tm, float* smem, int tid) {
+// `pair_here`: no role-B workgroup covers these rows (large grids: dsat_api.hip, plan_pair_blocks): the tile runs the
+// output / query pair itself, as two split chains on its 32 rows, between the PairNorm and lit_mlp.  The pre-mix state
+// leaves the PairNorm as planes behind the fp32 rows, the chains' hidden planes follow them -- all inside h1's space,
+// which lit_mlp's first layer only overwrites afterwards; the query chain reads the v1 planes lit_mlp reads too.
+__device__ __forceinline__ void role_a2(const RoundArgs& a, int tile, const TileMetaDev& tm, float* smem, int tid,
+                                        bool pair_here) {
     constexpr int BM = 32, PD = DSAT_SPLIT_PD4;
     constexpr int KS0 = (F + AUX_W + 31) / 32, LDX = KS0 * 32 + 16, HID = 512, LD1 = HID + 16, LD2 = HID / 2 + 16;
     constexpr int KS1 = HID / 32, KS2 = HID / 32;
@@ -565,23 +570,70 @@ __device__ __forceinline__ void role_a2(const RoundArgs& a, int tile, const Tile
         const int n = tile_lo + tid;
         load_aux_row(sState + tid * ldS + F, a.aux, n, N, a.round, n < N && !a.tail);
     }
+    // pair in the tile: the pre-mix state as planes [3][32][bo_ld] behind the fp32 rows and their partial sums
+    unsigned short* xo = reinterpret_cast<unsigned short*>(sPart + (NT / F) * F);
+    unsigned short* hp = xo + 3 * BM * a.bo_ld;                                         // hidden planes of either chain
     pairnorm_tile<BM>(tile_lo, N, tm, a.var_seg, a.vgseg, a.psum_v, a.vgseg2, a.psum2_v, a.newv, a.V_in, a.V_out,
-                      a.round == 0, sState, ldS, nullptr, 0, sMean, sPart, F, tid, a.inv_f, a.fm);
+                      a.round == 0, sState, ldS, nullptr, 0, sMean, sPart, F, tid, a.inv_f, a.fm,
+                      pair_here ? xo : nullptr, a.bo_ld);
     DSAT_STAMP(a, 1);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    // v1 = [state | aux | zeros up to the last k-step] as slices
+    auto slice_v1 = [&]() {
+        for (int i = tid; i < BM * (KS0 * 8); i += NT) {
+            const int r = i / (KS0 * 8), c = 4 * (i % (KS0 * 8));
+            const float4 v = c < F + AUX_W ? ld4(sState + r * ldS + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            split_st4(r2, BM * LDX, r * LDX + c, v);
+        }
+    };
+    if (pair_here && a.round > 0) {   // R14: logits of the previous round from the pre-mix state
+        float* lg = a.logits;
+        float* tr = a.trace_logits != nullptr ? a.trace_logits + (size_t)(a.round - 1) * N * LOGIT_MAPS : nullptr;
+        SplitChain so;
+        so.nlayers = 2;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) so.L[l] = SplitLayer{a.bo_ws[l < 2 ? l : 0], a.mout4.L[l < 2 ? l : 0].bias, a.bo_ks[l < 2 ? l : 0], a.bo_nt[l < 2 ? l : 0]};
+        split_chain<2, NT, PD>(so, xo, a.bo_ld, hp, hp, a.bo_ld, wv, lane, tid, [=](int row, int col, float4 v) {
+            int n = tile_lo + row;
+            NO_HOIST(n);
+            if (n < N && col < LOGIT_MAPS) {
+                stg4(lg + (size_t)n * LOGIT_MAPS + col, v);
+                if (tr != nullptr) st4(tr + (size_t)n * LOGIT_MAPS + col, v);
+            }
+        }, [] {});
+    }
     DSAT_STAMP(a, 2);
-    DSAT_STAMP(a, 3);
-    if (a.tail) {   // the tail launch only finishes the PairNorm (role B makes the logits)
+    if (a.tail) {   // the tail launch only finishes the PairNorm (and makes the logits where no role B does)
+        DSAT_STAMP(a, 3);
         DSAT_STAMP(a, 4);
         DSAT_STAMP_RT_END(a);
         return;
     }
-    // v1 = [state | aux | zeros up to the last k-step] as slices
-    for (int i = tid; i < BM * (KS0 * 8); i += NT) {
-        const int r = i / (KS0 * 8), c = 4 * (i % (KS0 * 8));
-        const float4 v = c < F + AUX_W ? ld4(sState + r * ldS + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        split_st4(r2, BM * LDX, r * LDX + c, v);
+    if (!pair_here) {
+        slice_v1();
+    } else {   // R2: query = variables_query(v1); softplus(+-query) feeds the clause gather (loss/sat.py:132-133); the v1
+        // slices are made as the chain's prep(), after its first weights have been requested
+        float* q = a.q;
+        float* sp = a.sp;
+        SplitChain sc;
+        sc.nlayers = 2;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) sc.L[l] = SplitLayer{a.sp_ws[l < 2 ? l : 0], a.mq4.L[l < 2 ? l : 0].bias, a.sp_ks[l < 2 ? l : 0], a.sp_nt[l < 2 ? l : 0]};
+        split_chain<2, NT, PD>(sc, r2, LDX, hp, hp, a.s_ld_hid, wv, lane, tid, [=](int row, int col, float4 v) {
+            int n = tile_lo + row;
+            NO_HOIST(n);
+            if (n < N && col < F) {
+                stg4(q + (size_t)n * F + col, v);
+                const float4 t = make_float4(log1pf(expf(-fabsf(v.x))), log1pf(expf(-fabsf(v.y))),
+                                             log1pf(expf(-fabsf(v.z))), log1pf(expf(-fabsf(v.w))));
+                stg4(sp + (size_t)n * F + col, make_float4(fmaxf(v.x, 0.f) + t.x, fmaxf(v.y, 0.f) + t.y,
+                                                          fmaxf(v.z, 0.f) + t.z, fmaxf(v.w, 0.f) + t.w));
+                stg4(sp + (size_t)(NL + n) * F + col, make_float4(fmaxf(-v.x, 0.f) + t.x, fmaxf(-v.y, 0.f) + t.y,
+                                                                fmaxf(-v.z, 0.f) + t.z, fmaxf(-v.w, 0.f) + t.w));
+            }
+        }, slice_v1);
     }
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    DSAT_STAMP(a, 3);
     const unsigned voff = (unsigned)lane * 16u;
     const int col4 = 4 * (lane >> 4), row = lane & 15;
     auto wb = [&](int l, int t, int ks) { return reinterpret_cast<const float4*>(a.a2_ws[l]) + ((size_t)t * ks * 3) * 64; };
@@ -733,6 +785,10 @@ __device__ __forceinline__ void role_a1s(const RoundArgs& a, int tile, const Til
 //   C  blocks after that: finish the clause PairNorm of the previous round (R10; depends on P2(r-1)
 //      only), off P2's critical path.
 // The carried state is double-buffered by round (V_in -> V_out): A and B both read the old state.
+// Two instantiations: A2 = role A on 32-row tiles (role_a2, which may run the pair itself) with roles B and C beside it;
+// !A2 = role A on 16-row tiles (role_a1s / the fp32 chains) with roles B and C.  One kernel holding every form of role
+// A is more than hipcc's register allocation digests once role_a2 carries its own pair ("illegal VGPR to SGPR copy").
+template <bool A2>
 __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     constexpr int BM = ROUND_BM_VAR;
@@ -750,13 +806,16 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
     const TileMetaDev tm = load_meta(roleB ? a.vmeta4 : (a.a2_tiles > 0 ? a.vmeta2 : a.vmeta), tile);
     if (both_arrived(done, tm) != 0) return;
 #if DSAT_ROUND_NWAVES == 16
-    if (roleA && a.a2_tiles > 0) {
-        role_a2(a, tile, tm, smem, tid);
-        return;
-    }
-    if (roleA && a.a1_split) {
-        role_a1s(a, tile, tm, smem, tid);
-        return;
+    if constexpr (A2) {
+        if (roleA) {
+            role_a2(a, tile, tm, smem, tid, a.pair_blocks == 0 || tile * 32 < a.pair_first * 64);
+            return;
+        }
+    } else {
+        if (roleA && a.a1_split) {
+            role_a1s(a, tile, tm, smem, tid);
+            return;
+        }
     }
 #endif
     if (!roleA && !roleB) {
@@ -871,6 +930,7 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p1_kern
         DSAT_STAMP_RT_END(a);
         return;
     }
+    if constexpr (A2) return;   // (role A was role_a2 above)
     const int tile_lo = tile * BM;
     float* sX = smem + a.off_x;
     float* sVlog = smem + a.off_vlog;
@@ -2142,7 +2202,11 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
 
 hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st) {
     const int tiles = (a.a2_tiles > 0 ? a.a2_tiles : (a.N + ROUND_BM_VAR - 1) / ROUND_BM_VAR) + a.pair_blocks + a.cn_blocks;
-    hipLaunchKernelGGL(round_p1_kernel, dim3(tiles), dim3(NT), 0, st, a);
+#if DSAT_ROUND_NWAVES == 16
+    if (a.a2_tiles > 0) hipLaunchKernelGGL(round_p1_kernel<true>, dim3(tiles), dim3(NT), 0, st, a);
+    else
+#endif
+    hipLaunchKernelGGL(round_p1_kernel<false>, dim3(tiles), dim3(NT), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {

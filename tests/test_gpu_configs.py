@@ -226,6 +226,44 @@ def test_config5_full_T128_sampler(rt):
     assert c["predictions"].ne(a["predictions"]).any()                  # another seed, another trajectory
 
 
+def test_32row_tiles_that_run_the_pair_themselves_match_oracle(rt, monkeypatch):
+    """role_a2 with pair_here (DSAT_P1_A2_PAIR=1): on a grid of more than one wave of workgroups the A tiles of the
+    first rows run variables_output / variables_query themselves as split chains and fewer role-B workgroups are
+    launched.  Off by default (no gain measured) but kept correct: 56 formulas of 100 variables (175 A32
+    tiles + 88 role-B groups > 256 CUs), planner costs that hand most rows to the tiles, per-round logits, query and
+    the carried state against the oracle, and against the default form."""
+    from diffusionsat_amd.batch import make_batch
+    from diffusionsat_amd.instances import planted_ksat
+    insts = [planted_ksat(100, 428, 3, seed=300 + i)[:2] for i in range(56)]
+    batch = make_batch(insts)
+    data = O.create_adj_matrices(insts)
+    ws = oracle_weights(9)
+    rounds = 3
+    d = draws(batch.n_vars, rounds, seed=6)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.6), noisy, d["normal"], d["labels"], rounds, early_exit=False,
+                           dt=np.float32, trace=("logits", "query"))
+    g, w = rt.Graph(batch), rt.Weights(ws)
+    outs = {}
+    for name, env in (("default", {"DSAT_P1_A2": "1"}),
+                      ("pair in tile", {"DSAT_P1_A2": "1", "DSAT_P1_A2_PAIR": "1", "DSAT_P1_A2_COST": "60,66,200"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = rt.Session(g, w, max_rounds=rounds)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert s.split_mask() & 4
+        out = s.diffusion_step(0.6, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds, early_exit=False,
+                               want_round_logits=True, tap_round=1)
+        got = out["round_logits"].cpu().numpy()
+        for r in range(rounds):
+            assert np.abs(got[r] - ref["trace"]["logits"][r]).max() < 2e-4, (name, r)
+        q = out["tap"]["query"].cpu().numpy()
+        assert np.abs(q - ref["trace"]["query"][1]).max() < 1e-4 * max(1.0, float(np.abs(ref["trace"]["query"][1]).max())), name
+        outs[name] = got
+    assert np.abs(outs["default"] - outs["pair in tile"]).max() < 1e-4
+
+
 def test_large_graph_select_parts_and_early_exit(rt):
     """One formula large enough to be cut into several select/SAT workgroups (more than 4096 clauses),
     spread over enough tiles for the level-2 PairNorm sums, with one literal in thousands of clauses:

@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of environment switches on bench.py: tools/gpu_ab_env.sh OUTDIR "CONFIGS" "NAME=ENV ..." (ENV: comma-separated K=V, or "-")
+# A/B of environment switches on bench.py: tools/gpu_ab_env.sh OUTDIR "CONFIGS" "NAME=ENV ..." (ENV: K=V joined by +, or "-")
 O=gpurun_out/$1; mkdir -p $O
 for c in $2; do for spec in $3; do
   n=${spec%%=*}; e=${spec#*=}; [ "$e" = "-" ] && e=""
-  env ${e//,/ } python bench.py --config $c --no-cpu-baseline --no-secondary > $O/cfg${c}_$n.json 2>&1
+  env ${e//+/ } python bench.py --config $c --no-cpu-baseline --no-secondary > $O/cfg${c}_$n.json 2>&1
 done; done
 python - "$O" <<'PY'
 import glob, json, os, sys
