@@ -2127,7 +2127,9 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
             // (Role-C rows BETWEEN the tile rows, DSAT_CN_P3=2, were measured and lost: a block holds a whole CU while it
             // waits for memory -- config 3: P3 227 us against 147 us with the blocks behind the tiles.)
             const int p3tiles = (actN + s->p3_bm - 1) / s->p3_bm;
-            const bool host_c = r + 1 < rounds && actC > 0 && !s->no_cn && s->cn_in_p3 > 0;
+            // (only where P1 cannot: with idle CUs of its own -- a single wave of workgroups -- P1 hosts role C for free,
+            // while behind P3's shorter tiles the same blocks cost 0.3-0.6 us per round: config 2 361.5 against 359.1 steps/s)
+            const bool host_c = r + 1 < rounds && actC > 0 && !s->no_cn && s->cn_in_p3 > 0 && (free_cus < 8 || s->cn_in_p3 >= 3);
             const int rem = p3tiles % s->n_cus;
             const int idle3 = p3tiles < s->n_cus ? s->n_cus - p3tiles : (rem == 0 ? 0 : s->n_cus - rem);
             a3.cn_blocks = 0;
