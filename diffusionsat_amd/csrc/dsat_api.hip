@@ -1692,7 +1692,7 @@ extern "C" int dsat_session_set_retire(dsat_session* s, int32_t enable) {
 
 extern "C" int dsat_session_set_supervised(dsat_session* s, int32_t supervised) {
     DSAT_REQUIRE(s != nullptr, DSAT_E_INVALID, "dsat_session_set_supervised: null session");
-    s->unsupervised = supervised ? 0 : 1;   // lives in the device control block: captured graphs need no rebuild
+    s->unsupervised = supervised ? 0 : 1;   // (its own captured graph: select/SAT is then a launch of its own per round)
     return DSAT_OK;
 }
 
@@ -2067,7 +2067,12 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
             break;
         }
         a2.round = r;
-        a2.s_enable = early_exit && r > 0;   // G extra blocks: select/SAT of round r-1
+        a2.s_enable = early_exit && r > 0 && !s->unsupervised;   // G extra blocks: select/SAT of round r-1
+        if (early_exit && r > 0 && s->unsupervised)   // supervised=False: the rule lives in the stand-alone kernel only
+            L.run(KC_SELECT_SAT, [&] {
+                launch_select_sat(s->g, s->sel_tab, act_graphs >= 0 ? act_graphs : s->n_sel, s->logits, s->ctl, s->pgl, s->best,
+                                  s->out_logits, s->assign, s->graph_unsat, r - 1, early_exit, st);
+            });
         a2.cs_ready = cn > 0 || cn3_prev > 0;
         a2.cs_ready_rows = cn3_prev > 0 ? cn3_rows : 0;
         {
@@ -2179,7 +2184,7 @@ static int run_step(dsat_session* s, hipStream_t st, int rounds, int early_exit,
         DSAT_HIP(hipGetLastError());
         return DSAT_OK;
     }
-    auto key = std::make_tuple(rounds, early_exit, mode, s->use_fused + 2 * s->p1_a2 + 4 * s->prefer_tp);
+    auto key = std::make_tuple(rounds, early_exit, mode, s->use_fused + 2 * s->p1_a2 + 4 * s->prefer_tp + 8 * s->unsupervised);
     auto it = s->graphs.find(key);
     if (it == s->graphs.end()) {
         hipGraph_t graph = nullptr;

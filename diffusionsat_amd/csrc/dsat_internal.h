@@ -277,11 +277,6 @@ struct RoundArgs {
                            // P3: the same for THIS round's clause state (round 3), behind the tiles (cn_period = 0) or,
                            //     on grids of several waves of workgroups, as whole rows of 8 blocks after every
                            //     cn_period rows of 8 tiles, so that their row streaming runs beside the tiles' MFMA work
-    int cn_period;         // P3: see cn_blocks
-    int cn_rows;           // role C covers clause rows [0, cn_rows) (a multiple of P2's tile height unless it is all of them)
-    int cs_ready_rows;     // P2: clause rows below this were normalised by a role C before this launch (replaces the
-                           //     all-or-nothing cs_ready for P3-hosted role C on large batches)
-    int p3_tiles;          // P3: variable tiles of the launch (the grid also holds the role-C blocks)
     int cs_ready;          // P2 only: clause_state was already normalised by P1's extra blocks
     int round;             // message-passing round this launch belongs to
     int check_done;        // early exit armed: skip when ctl->done
@@ -336,12 +331,6 @@ struct RoundArgs {
     const uint4* d_ws;
     float* upd_part;
     const uint4* a2_ws[3];  // lit_mlp's three layers as bf16 slices
-    // P1 role B: variables_output (128 -> 128 -> 8) as split products as well: the PairNorm of the 64-row tile emits the
-    // pre-mix state as planes.  bo_ws[0] == nullptr: the fp32-MFMA chain (mout4).  LDS plan in float offsets: input
-    // planes, hidden planes, the query chain's v1 planes afterwards, the PairNorm means; bo_ld: row stride, bf16 elements
-    const uint4* bo_ws[2];
-    int bo_ks[2], bo_nt[2];
-    int bo_off_x, bo_off_h, bo_off_xq, bo_off_mean, bo_ld;
     // P2 / P3 with fp32 products formed from bf16 slices (round_p2s_kernel, round_p3s_kernel, split_bf16.h): per
     // layer the weights as three bf16 planes in fragment order, k-steps of 32 and column tiles; LDS plan in
     // BYTES / bf16 elements (P3: s_buf1 = the input planes, s_buf2 = hidden A then hidden B)
@@ -354,6 +343,19 @@ struct RoundArgs {
     int s_ld_seg, s_ld_hid;                         // row strides of the plane images, bf16 elements
     // LDS plan (float offsets / row strides), filled by plan_round_lds
     int ld_x, ld_a, ld_b, ld_v, off_x, off_a, off_b, off_vlog, off_mean;   // ld_v: row stride of the pre-mix state tile
+    // ---- round 3 (appended: the offsets of everything above are those of the round-2 kernels, whose register
+    // allocation -- P2's in particular, 76 scalar spills -- shifts with them: 1 % of a config-2 step, measured)
+    // P1 role B: variables_output (128 -> 128 -> 8) as split products as well: the PairNorm of the 64-row tile emits the
+    // pre-mix state as planes.  bo_ws[0] == nullptr: the fp32-MFMA chain (mout4).  LDS plan in float offsets: input
+    // planes, hidden planes, the query chain's v1 planes afterwards, the PairNorm means; bo_ld: row stride, bf16 elements
+    const uint4* bo_ws[2];
+    int bo_ks[2], bo_nt[2];
+    int bo_off_x, bo_off_h, bo_off_xq, bo_off_mean, bo_ld;
+    int cn_period;         // P3: see cn_blocks
+    int cn_rows;           // role C covers clause rows [0, cn_rows) (a multiple of P2's tile height unless it is all of them)
+    int cs_ready_rows;     // P2: clause rows below this were normalised by a role C before this launch (replaces the
+                           //     all-or-nothing cs_ready for P3-hosted role C on large batches)
+    int p3_tiles;          // P3: variable tiles of the launch (the grid also holds the role-C blocks)
 };
 constexpr int TILE_META_INTS = 16;
 constexpr int LIST_BLOCK_LOADS = 4;    // ints per thread with which a workgroup fetches a tile's list block

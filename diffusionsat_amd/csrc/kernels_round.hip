@@ -139,6 +139,9 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles) {
 struct P3Slot { bool is_c; int idx; };
 __device__ __forceinline__ P3Slot p3_slot(const RoundArgs& a) {
     const int b = (int)blockIdx.x;
+#ifdef DSAT_P3_NO_ROLEC   // experiment switch: P3's grid holds tiles only (what role C's dispatch costs the tiles)
+    return P3Slot{false, b};
+#endif
     if (a.cn_period <= 0) return b >= a.p3_tiles ? P3Slot{true, b - a.p3_tiles} : P3Slot{false, b};
     const int j = b >> 3, x = b & 7, cyc = a.cn_period + 1, c_rows = (a.cn_blocks + 7) >> 3;
     const int i = j / cyc;
@@ -456,7 +459,7 @@ __device__ __forceinline__ void list_block_store(const ListBlock& lb, int* dst, 
 }
 
 // R15-R17 for one graph (forward declaration; defined with the stand-alone kernel below)
-template <int NTH>
+template <int NTH, bool UNSUP = false>
 __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int32_t* __restrict__ sel_tab,
                                 const int32_t* __restrict__ vseg,
                                 const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
@@ -1731,8 +1734,10 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3_kern
 // reuses the input planes.  With 16-row tiles the chain is bound by the weight stream (6 bytes per weight through
 // the CU's 64 B/clk vector-memory path), not by the MFMA pipe.
 #if DSAT_ROUND_NWAVES == 16
-template <int BM>   // 16 rows, or 32 (two row blocks per weight fragment: half the weight stream per row; the
-                    // PairNorm segment tables of the session are then built for 32-row producer tiles)
+template <int BM, bool HOSTC>   // BM: 16 rows, or 32 (two row blocks per weight fragment: half the weight stream per row; the
+                    // PairNorm segment tables of the session are then built for 32-row producer tiles).  HOSTC: the grid
+                    // also holds role-C blocks (cn_blocks > 0); the tiles-only form pays nothing for their dispatch
+                    // (0.45 % of a config-2 step when it was a runtime test)
 __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     constexpr int PASSES = BM / ROUND_NWAVES;   // variables per wave
@@ -1744,9 +1749,9 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p3s_ker
     const int N = a.N, NL = a.NL;
     // role C: the blocks behind the tiles finish the clause PairNorm (R10) of THIS round for P2 of the next one, on the
     // CUs the last wave of tiles leaves idle (dsat_api.hip, cn3)
-    const P3Slot slot = p3_slot(a);
-    const bool roleC = slot.is_c || slot.idx >= a.p3_tiles;
-    const int tile = roleC ? 0 : xcd_tile(slot.idx, a.p3_tiles);
+    const P3Slot slot = HOSTC ? p3_slot(a) : P3Slot{false, (int)blockIdx.x};
+    const bool roleC = HOSTC && (slot.is_c || slot.idx >= a.p3_tiles);
+    const int tile = roleC ? 0 : xcd_tile(slot.idx, HOSTC ? a.p3_tiles : (int)gridDim.x);
     const int done = a.check_done ? a.ctl->done : 0;   // requested together with the tile record
     const TileMetaDev tm = load_meta(a.vmeta, tile);
     ListBlock lb;                                       // ... and with the tile's literal -> clause lists
@@ -2064,7 +2069,11 @@ __device__ __forceinline__ float bern_kl(float a, float b) {
 // bits of ITS slice of the variables and checks ITS slice of the clauses, taking literal values
 // straight from the logits, so no part waits for another's bits.  Unsatisfied-clause counts meet in
 // graph_unsat (integer atomics; zeroed by P3 before every select when parts > 1).
-template <int NTH>
+// UNSUP: also built for QuerySAT(supervised=False) (the clause-loss rule).  Only the stand-alone select_sat_kernel is: the
+// copies that ride in P2's grid stay as they were -- the extra code in front of P2's tile loops cost config 2 0.5 % (its
+// placement, not its execution: the branch is never taken there) -- and an unsupervised session launches the kernel
+// between P1 and P2 instead (dsat_api.hip).
+template <int NTH, bool UNSUP>
 __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int32_t* __restrict__ sel_tab,
                                 const int32_t* __restrict__ vseg,
                                 const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
@@ -2085,9 +2094,12 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
     float acc[LOGIT_MAPS];
 #pragma unroll
     for (int k = 0; k < LOGIT_MAPS; ++k) acc[k] = 0.f;
-    const bool unsup = ctl->unsupervised != 0;
-    if (unsup)   // supervised=False: the graph's own clause loss per logit map (every part recomputes all of it)
-        for (int c = cseg[g] + tid; c < cseg[g + 1]; c += NTH) unsup_clause_loss8(logits, rowptr, c_lit, c, N, acc);
+    bool unsup = false;
+    if constexpr (UNSUP) {
+        unsup = ctl->unsupervised != 0;
+        if (unsup)   // supervised=False: the graph's own clause loss per logit map (every part recomputes all of it)
+            for (int c = cseg[g] + tid; c < cseg[g + 1]; c += NTH) unsup_clause_loss8(logits, rowptr, c_lit, c, N, acc);
+    }
     for (int v = v0 + tid; v < v1 && !unsup; v += NTH) {
         int label;
         if (ctl->inj_labels != nullptr) {
@@ -2194,7 +2206,7 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
     uint8_t* __restrict__ assign, int32_t* __restrict__ graph_unsat, int N, int round, int set_done) {
     if (set_done && ctl->done != 0) return;
     __shared__ float sred[256 * (LOGIT_MAPS + 1) + 2];
-    select_sat_body<256>(blockIdx.x, gridDim.x, sel_tab, vseg, cseg, rowptr, c_lit, logits, ctl, pgl, best, out_logits,
+    select_sat_body<256, true>(blockIdx.x, gridDim.x, sel_tab, vseg, cseg, rowptr, c_lit, logits, ctl, pgl, best, out_logits,
                          assign, graph_unsat, N, round, set_done, sred);
 }
 
@@ -2233,8 +2245,14 @@ hipError_t launch_round_p3(const RoundArgs& a0, hipStream_t st) {
     const int grid = a.cn_period > 0 ? 8 * ((a.p3_tiles + 7) / 8 + (a.cn_blocks + 7) / 8) : a.p3_tiles + a.cn_blocks;
 #if DSAT_ROUND_NWAVES == 16
     if (a.sp_ws[0] != nullptr) {
-        if (a.p3_bm == 32) hipLaunchKernelGGL(round_p3s_kernel<32>, dim3(grid), dim3(NT), 0, st, a);
-        else hipLaunchKernelGGL(round_p3s_kernel<16>, dim3(grid), dim3(NT), 0, st, a);
+        const bool hc = a.cn_blocks > 0;
+        if (a.p3_bm == 32) {
+            if (hc) hipLaunchKernelGGL((round_p3s_kernel<32, true>), dim3(grid), dim3(NT), 0, st, a);
+            else hipLaunchKernelGGL((round_p3s_kernel<32, false>), dim3(grid), dim3(NT), 0, st, a);
+        } else {
+            if (hc) hipLaunchKernelGGL((round_p3s_kernel<16, true>), dim3(grid), dim3(NT), 0, st, a);
+            else hipLaunchKernelGGL((round_p3s_kernel<16, false>), dim3(grid), dim3(NT), 0, st, a);
+        }
         return hipGetLastError();
     }
 #endif
