@@ -772,6 +772,7 @@ struct dsat_session {
     float *x0b = nullptr, *x1b = nullptr;   // second x buffers (the survivors move between steps)
     int32_t* n_act_host = nullptr;          // pinned
     int no_cn = 0;                 // DSAT_NO_CN (ablation): P2 finishes the clause PairNorm itself
+    int sel_pack_on = 1;           // DSAT_SEL_PACK=0: one select/SAT workgroup per graph always
     int cn_in_p3 = 1;              // role C rides in P3's grid when its last wave of tiles leaves CUs idle (DSAT_CN_P3=0: only in P1's)
     double cn_frac = 1.0;          // ... on grids of several waves: this share of the clause rows (DSAT_CN_P3_FRAC; 0.5 / 0.75 measured: less gain)
     char* slab = nullptr;
@@ -1352,6 +1353,7 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
     s->g = g; s->w = w; s->max_rounds = max_rounds;
     s->no_cn = getenv("DSAT_NO_CN") != nullptr;
     { const char* e = getenv("DSAT_CN_P3"); s->cn_in_p3 = e == nullptr ? 1 : atoi(e); }
+    { const char* e = getenv("DSAT_SEL_PACK"); s->sel_pack_on = !(e != nullptr && e[0] == '0'); }
     { const char* e = getenv("DSAT_P1_A2_PAIR"); s->a2_pair_here = e != nullptr && e[0] == '1'; }
     { const char* e = getenv("DSAT_P1_A2_COST");     // "with,without,b" in k cycles (planning experiments)
       if (e != nullptr) sscanf(e, "%lf,%lf,%lf", &s->a2_cost[0], &s->a2_cost[1], &s->a2_cost[2]); }
@@ -2068,6 +2070,10 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         }
         a2.round = r;
         a2.s_enable = early_exit && r > 0 && !s->unsupervised;   // G extra blocks: select/SAT of round r-1
+        // ... or G / 4: with hundreds of small graphs (config 3: 256) one 1024-thread workgroup per graph is a whole extra
+        // wave of P2's grid for 100 variables each; four graphs share a workgroup then, 256 threads each
+        // (not where the select workgroups double as role-D workers: that is the small-batch regime anyway)
+        a2.sel_pack = 1;
         if (early_exit && r > 0 && s->unsupervised)   // supervised=False: the rule lives in the stand-alone kernel only
             L.run(KC_SELECT_SAT, [&] {
                 launch_select_sat(s->g, s->sel_tab, act_graphs >= 0 ? act_graphs : s->n_sel, s->logits, s->ctl, s->pgl, s->best,
@@ -2085,6 +2091,9 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
             int workers = 0, dsel = 0;
             const int extra_blocks = role_d_blocks(s, actN, actC, a2.s_enable != 0, a2.sel_lead, a2.n_sel, &workers, &dsel);
             const bool part = extra_blocks > 0;
+            if (!part && s->sel_pack_on && a2.s_enable && a2.sel_lead == 0 && a2.n_sel >= 64 &&
+                (actN + a2.n_sel - 1) / a2.n_sel <= 1024)
+                a2.sel_pack = 4;
             a2.d_blocks = extra_blocks;
             a2.d_sel = dsel;
             a2.d_workers = workers;

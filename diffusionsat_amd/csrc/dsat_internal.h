@@ -351,6 +351,7 @@ struct RoundArgs {
     const uint4* bo_ws[2];
     int bo_ks[2], bo_nt[2];
     int bo_off_x, bo_off_h, bo_off_xq, bo_off_mean, bo_ld;
+    int sel_pack;          // P2: graphs per select/SAT workgroup (1, or 4 x 256 threads on batches of many small graphs)
     int cn_period;         // P3: see cn_blocks
     int cn_rows;           // role C covers clause rows [0, cn_rows) (a multiple of P2's tile height unless it is all of them)
     int cs_ready_rows;     // P2: clause rows below this were normalised by a role C before this launch (replaces the

@@ -466,7 +466,8 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
                                 const int32_t* __restrict__ c_lit, const float* __restrict__ logits,
                                 Ctl* __restrict__ ctl, float* __restrict__ pgl, int32_t* __restrict__ best,
                                 float* __restrict__ out_logits, uint8_t* __restrict__ assign,
-                                int32_t* __restrict__ graph_unsat, int N, int round, int set_done, float* sred);
+                                int32_t* __restrict__ graph_unsat, int N, int round, int set_done, float* sred,
+                                int tid = (int)threadIdx.x, bool active = true);
 
 // R10 for a contiguous range of clause rows (one of `nb` extra workgroups of P1): same arithmetic
 // as pairnorm_tile, streamed; clause_state is updated in place for P2 to load.
@@ -1022,7 +1023,8 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
     // the tiles keep their XCD mapping.
     const int lead = a.s_enable ? a.sel_lead : 0;
     const int tb = (int)blockIdx.x - lead;
-    if (tb < 0 && (int)blockIdx.x >= a.n_sel) return;
+    const int nsb = a.sel_pack > 1 ? (a.n_sel + a.sel_pack - 1) / a.sel_pack : a.n_sel;   // select workgroups
+    if (tb < 0 && (int)blockIdx.x >= nsb) return;
     const bool extra = tb < 0 || tb >= tiles;
     const int sel_blk = tb < 0 ? (int)blockIdx.x : tb - tiles;
     const int tile = extra ? 0 : xcd_tile(tb, tiles);
@@ -1034,6 +1036,14 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2_kern
     if (extra) {
         DSAT_STAMP_RT_BEGIN(a);
         DSAT_STAMP(a, 0);
+        if (a.sel_pack > 1) {   // four graphs per workgroup, 256 threads each (large batches of small graphs: a select
+            // workgroup per graph would be a whole extra wave of workgroups, 256 at config 3)
+            const int sub = tid >> 8, e = sel_blk * 4 + sub;
+            const bool act = e < a.n_sel;
+            select_sat_body<256>(act ? e : a.n_sel - 1, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit,
+                                 a.logits, a.ctl, a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, NL, a.round - 1,
+                                 a.check_done, smem + sub * 2560, tid & 255, act);
+        } else
         select_sat_body<NT>(sel_blk, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
                             a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, NL, a.round - 1, a.check_done,
                             smem);
@@ -1256,7 +1266,8 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
     const int tiles = (C + BM - 1) / BM;
     const int lead = a.s_enable ? a.sel_lead : 0;
     const int tb = (int)blockIdx.x - lead;
-    if (tb < 0 && (int)blockIdx.x >= a.n_sel) return;
+    const int nsb = a.sel_pack > 1 ? (a.n_sel + a.sel_pack - 1) / a.sel_pack : a.n_sel;   // select workgroups
+    if (tb < 0 && (int)blockIdx.x >= nsb) return;
     const bool extra = tb < 0 || tb >= tiles;
     const int sel_blk = tb < 0 ? (int)blockIdx.x : tb - tiles;
     const int tile = extra ? 0 : xcd_tile(tb, tiles);
@@ -1285,6 +1296,14 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
         }
         DSAT_STAMP_RT_BEGIN(a);
         DSAT_STAMP(a, 0);
+        if (a.sel_pack > 1) {   // four graphs per workgroup, 256 threads each (large batches of small graphs: a select
+            // workgroup per graph would be a whole extra wave of workgroups, 256 at config 3)
+            const int sub = tid >> 8, e = sel_blk * 4 + sub;
+            const bool act = e < a.n_sel;
+            select_sat_body<256>(act ? e : a.n_sel - 1, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit,
+                                 a.logits, a.ctl, a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, NL, a.round - 1,
+                                 a.check_done, smem + sub * 2560, tid & 255, act);
+        } else
         select_sat_body<NT>(sel_blk, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
                             a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, NL, a.round - 1, a.check_done,
                             smem);
@@ -2080,12 +2099,15 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
                                 const int32_t* __restrict__ c_lit, const float* __restrict__ logits,
                                 Ctl* __restrict__ ctl, float* __restrict__ pgl, int32_t* __restrict__ best,
                                 float* __restrict__ out_logits, uint8_t* __restrict__ assign,
-                                int32_t* __restrict__ graph_unsat, int N, int round, int set_done, float* sred) {
-    // sred: NTH*(LOGIT_MAPS+1) + 2 floats of LDS
+                                int32_t* __restrict__ graph_unsat, int N, int round, int set_done, float* sred,
+                                int tid, bool active) {
+    // sred: NTH*(LOGIT_MAPS+1) + 2 floats of LDS.  tid / active: several entries may share a workgroup (P2's packed
+    // select blocks: NTH threads each, tid = the thread's index within its entry, every barrier below is taken by all
+    // of them together -- entries with parts == 1 only); an inactive sub-block mirrors a valid entry's control flow
+    // and writes nothing.
     float (*red)[LOGIT_MAPS + 1] = reinterpret_cast<float (*)[LOGIT_MAPS + 1]>(sred);
     int* s_best = reinterpret_cast<int*>(sred + NTH * (LOGIT_MAPS + 1));
     int* s_unsat = s_best + 1;
-    const int tid = threadIdx.x;
     const int g = sel_tab[4 * blk], part = sel_tab[4 * blk + 1], parts = sel_tab[4 * blk + 2];
     const int v0 = vseg[g], v1 = vseg[g + 1];
     const float t = powf(ctl->noise_scale, 0.5f);
@@ -2134,20 +2156,20 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
         const float inv = 1.f / (float)(v1 - v0);
         int bi = 0;
         float bv = unsup ? unsup_graph_loss(red[0][0]) : red[0][0] * inv;
-        if (part == 0) pgl[g * LOGIT_MAPS] = bv;
+        if (part == 0 && active) pgl[g * LOGIT_MAPS] = bv;
         for (int k = 1; k < LOGIT_MAPS; ++k) {
             const float x = unsup ? unsup_graph_loss(red[0][k]) : red[0][k] * inv;
-            if (part == 0) pgl[g * LOGIT_MAPS + k] = x;
+            if (part == 0 && active) pgl[g * LOGIT_MAPS + k] = x;
             if (x < bv) { bv = x; bi = k; }   // first minimum wins, as TF's CPU ArgMin
         }
-        if (part == 0) best[g] = bi;
+        if (part == 0 && active) best[g] = bi;
         *s_best = bi;
     }
     __syncthreads();
     const int bi = *s_best;
     {   // this part's slice of the variables
         const int per = (v1 - v0 + parts - 1) / parts;
-        const int a0 = v0 + part * per, a1 = min(a0 + per, v1);
+        const int a0 = v0 + part * per, a1 = active ? min(a0 + per, v1) : a0;
         for (int v = a0 + tid; v < a1; v += NTH) {
             const float x = logits[(size_t)v * LOGIT_MAPS + bi];
             out_logits[v] = x;
@@ -2182,7 +2204,7 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
     }
     if (unsat) atomicAdd(s_unsat, unsat);
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && active) {
         if (parts == 1) graph_unsat[g] = *s_unsat;
         else if (*s_unsat) atomicAdd(&graph_unsat[g], *s_unsat);
         if (*s_unsat) atomicAdd(&ctl->unsat_total, *s_unsat);
@@ -2223,7 +2245,8 @@ hipError_t launch_round_p1(const RoundArgs& a, hipStream_t st) {
 }
 hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {
     const int bm = 16 * rb;
-    const int tiles = (a.C + bm - 1) / bm + (a.s_enable ? (a.sel_lead > 0 ? a.sel_lead : a.n_sel) : 0);
+    const int nsb = a.sel_pack > 1 ? (a.n_sel + a.sel_pack - 1) / a.sel_pack : a.n_sel;
+    const int tiles = (a.C + bm - 1) / bm + (a.s_enable ? (a.sel_lead > 0 ? a.sel_lead : nsb) : 0);
     if (tiles == 0) return hipSuccess;
 #if DSAT_ROUND_NWAVES == 16
     if (rb == 4 && a.sp_ws[0] != nullptr) {
