@@ -291,18 +291,22 @@ class QuerySAT:
         self.logit_maps = 8
         self.prediction_tries = 1
         self.device = torch.device(device)
-        # the reference's constructor, line for line in meaning (model/query_sat.py:101-122)
-        update_layers, output_layers, query_layers, clauses_layers = 3, 2, 2, 2
-        update_scale, output_scale, clauses_scale, query_scale = 1.8, 1, 1.6, 1.2
-        self.variables_norm = PairNorm(subtract_mean=True)
-        self.clauses_norm = PairNorm(subtract_mean=True)
-        self.update_gate = MLP(update_layers, int(feature_maps * update_scale), feature_maps, name="update_gate", do_layer_norm=False)
-        self.variables_output = MLP(output_layers, int(feature_maps * output_scale), self.logit_maps, name="variables_output", do_layer_norm=False)
-        self.variables_query = MLP(query_layers, int(query_maps * query_scale), query_maps, name="variables_query", do_layer_norm=False)
-        self.clause_mlp = MLP(clauses_layers, int(feature_maps * clauses_scale), feature_maps + 1 * query_maps, name="clause_update", do_layer_norm=False)
-        self.lit_mlp = MLP(msg_layers, query_maps * 4, query_maps * 2, name="lit_query", do_layer_norm=False)
-        self._mlps = {"update_gate": self.update_gate, "variables_output": self.variables_output,
-                      "variables_query": self.variables_query, "clause_mlp": self.clause_mlp, "lit_mlp": self.lit_mlp}
+        # the five MLPs and two PairNorms of the reference's constructor (model/query_sat.py:101-122): attribute name ->
+        # (layer count, hidden width, output width, Keras layer name); the width factors are the reference's defaults
+        # (update 1.8, output 1, query 1.2, clauses 1.6; lit_mlp 4 x query_maps wide, 2 x query_maps out)
+        fm, qm = int(feature_maps), int(query_maps)
+        shapes = {
+            "update_gate": (3, int(fm * 1.8), fm, "update_gate"),
+            "variables_output": (2, int(fm * 1), self.logit_maps, "variables_output"),
+            "variables_query": (2, int(qm * 1.2), qm, "variables_query"),
+            "clause_mlp": (2, int(fm * 1.6), fm + qm, "clause_update"),
+            "lit_mlp": (int(msg_layers), qm * 4, qm * 2, "lit_query"),
+        }
+        self._mlps = {attr: MLP(n, hidden, out, name=keras_name, do_layer_norm=False)
+                      for attr, (n, hidden, out, keras_name) in shapes.items()}
+        for attr, mlp in self._mlps.items():
+            setattr(self, attr, mlp)
+        self.variables_norm, self.clauses_norm = PairNorm(subtract_mean=True), PairNorm(subtract_mean=True)
         # the same shape as a dsat_layout for the fused kernels
         self.layout = _lib.default_layout()
         self.layout.feature_maps, self.layout.query_maps = int(feature_maps), int(query_maps)
