@@ -2025,18 +2025,26 @@ __global__ __launch_bounds__(1024) void segsum2_kernel(const int2* __restrict__ 
 // order), the eight sums are combined in half-wave order: deterministic, no atomics.
 // (The same kernel serves heavy CLAUSES before P2: idx = the clause's literal rows, the arrays sp / lits,
 // the zero row 2*N.)
-__global__ __launch_bounds__(256) void heavy_gather_kernel(const int2* __restrict__ pieces,
+#ifndef DSAT_HEAVY_NHW
+#define DSAT_HEAVY_NHW 8      // half-waves per piece
+#endif
+#ifndef DSAT_HEAVY_GJ
+#define DSAT_HEAVY_GJ 4       // rows in flight per half-wave and array
+#endif
+// (16 half-waves with 8 rows in flight each -- a quarter of the dependent round trips per piece -- left the launch at
+// 18.9 us at config 5: it moves ~100 MB of rows that no longer fit L2, and that is what it takes.)
+__global__ __launch_bounds__(32 * DSAT_HEAVY_NHW) void heavy_gather_kernel(const int2* __restrict__ pieces,
                                                            const int32_t* __restrict__ l_clause,
                                                            const float* __restrict__ closs4,
                                                            const float* __restrict__ vla, int C,
                                                            float* __restrict__ hpart, const int* __restrict__ done) {
     if (done != nullptr && *done != 0) return;
-    __shared__ float4 red[8][2][32];
-    constexpr int GJ = 4;
+    constexpr int NHW = DSAT_HEAVY_NHW, GJ = DSAT_HEAVY_GJ;
+    __shared__ float4 red[NHW][2][32];
     const int sub = threadIdx.x & 31, hw = threadIdx.x >> 5;
     const int2 pc = pieces[blockIdx.x];
     const int len = pc.y - pc.x;
-    const int per = ((len + 7) / 8 + GJ - 1) / GJ * GJ;
+    const int per = ((len + NHW - 1) / NHW + GJ - 1) / GJ * GJ;
     const int e0 = pc.x + hw * per, e1 = min(e0 + per, pc.y);
     float4 M = make_float4(0.f, 0.f, 0.f, 0.f), VL = M;
     const unsigned zrow = (unsigned)C;   // the all-zero pad row of closs4 / vla
@@ -2060,11 +2068,11 @@ __global__ __launch_bounds__(256) void heavy_gather_kernel(const int2* __restric
     red[hw][0][sub] = M;
     red[hw][1][sub] = VL;
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 64) {   // the half-waves' sums in half-wave order: one fixed order, run to run
         const int arr = threadIdx.x >> 5;
         float4 t = red[0][arr][sub];
 #pragma unroll
-        for (int h = 1; h < 8; ++h) {
+        for (int h = 1; h < NHW; ++h) {
             const float4 u = red[h][arr][sub];
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
@@ -2291,8 +2299,8 @@ hipError_t launch_segsum2(const int2* chunks, int n_chunks, const float* psum, f
 hipError_t launch_heavy_gather(const int2* pieces, int n_pieces, const int32_t* l_clause, const float* closs4,
                                const float* vla, int C, float* hpart, const int* done, hipStream_t st) {
     if (n_pieces <= 0) return hipSuccess;
-    hipLaunchKernelGGL(heavy_gather_kernel, dim3(n_pieces), dim3(256), 0, st, pieces, l_clause, closs4, vla, C, hpart,
-                       done);
+    hipLaunchKernelGGL(heavy_gather_kernel, dim3(n_pieces), dim3(32 * DSAT_HEAVY_NHW), 0, st, pieces, l_clause, closs4, vla, C,
+                       hpart, done);
     return hipGetLastError();
 }
 void launch_select_sat(const dsat_graph* g, const int32_t* sel_tab, int n_sel, const float* logits, Ctl* ctl,
