@@ -772,6 +772,7 @@ struct dsat_session {
     float *x0b = nullptr, *x1b = nullptr;   // second x buffers (the survivors move between steps)
     int32_t* n_act_host = nullptr;          // pinned
     int no_cn = 0;                 // DSAT_NO_CN (ablation): P2 finishes the clause PairNorm itself
+    int cn_p1_tail = -1;           // role C in the last wave of a multi-wave P1 instead of P3's: -1 by rule, DSAT_CN_P1_TAIL=0/1
     int sel_pack_on = 1;           // DSAT_SEL_PACK=0: one select/SAT workgroup per graph always
     int cn_in_p3 = 1;              // role C rides in P3's grid when its last wave of tiles leaves CUs idle (DSAT_CN_P3=0: only in P1's)
     double cn_frac = 1.0;          // ... on grids of several waves: this share of the clause rows (DSAT_CN_P3_FRAC; 0.5 / 0.75 measured: less gain)
@@ -1354,6 +1355,7 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
     s->no_cn = getenv("DSAT_NO_CN") != nullptr;
     { const char* e = getenv("DSAT_CN_P3"); s->cn_in_p3 = e == nullptr ? 1 : atoi(e); }
     { const char* e = getenv("DSAT_SEL_PACK"); s->sel_pack_on = !(e != nullptr && e[0] == '0'); }
+    { const char* e = getenv("DSAT_CN_P1_TAIL"); if (e != nullptr) s->cn_p1_tail = e[0] == '1' ? 1 : 0; }
     { const char* e = getenv("DSAT_P1_A2_PAIR"); s->a2_pair_here = e != nullptr && e[0] == '1'; }
     { const char* e = getenv("DSAT_P1_A2_COST");     // "with,without,b" in k cycles (planning experiments)
       if (e != nullptr) sscanf(e, "%lf,%lf,%lf", &s->a2_cost[0], &s->a2_cost[1], &s->a2_cost[2]); }
@@ -2049,7 +2051,20 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
             a1.pair_first = pb_first;
         }
         a1.a1_split = s->p1_a1s && !s->p1_a2 && !a1.tail && a1.pair_first == 0 && a1.pair_blocks == (actN + 63) / 64;
-        const int free_cus = s->n_cus - (s->p1_a2 ? a1.a2_tiles : vtiles) - a1.pair_blocks;
+        // CUs without a P1 workgroup: all but the workgroups' own in a single wave; with DSAT_CN_P1_TAIL=1 also those of
+        // the last wave of a larger grid (the role-C blocks are the last of the grid)
+        const int p1_blocks = (s->p1_a2 ? a1.a2_tiles : vtiles) + a1.pair_blocks;
+        int free_cus = s->n_cus - p1_blocks;
+        if (p1_blocks > s->n_cus) {
+            // Several waves of workgroups: the CUs the LAST wave leaves idle can host role C too (its blocks are the last
+            // of the grid) -- when that wave still holds A tiles, which last long enough to cover a block's row streaming
+            // (config 5: 57 A tiles in the last wave, P3 75 -> 66 us for P1 + 0.5 us, 97.0 -> 99.0 steps/s); a last wave
+            // of role-B workgroups alone is too short (config 3: P1 189 -> 228 us): P3's tail hosts it then (below)
+            const int rem = p1_blocks % s->n_cus, idle1 = rem ? s->n_cus - rem : 0;
+            const bool a_in_last = rem > a1.pair_blocks;
+            const bool want = s->cn_p1_tail == 1 || (s->cn_p1_tail < 0 && a_in_last && idle1 >= 8 && (int64_t)actC <= (int64_t)idle1 * 1500);
+            free_cus = want ? idle1 : 0;
+        }
         const int cn = (r > 0 && r < rounds && actC > 0 && free_cus >= 8 && !s->no_cn && cn3_prev == 0) ? free_cus : 0;
         a1.cn_blocks = cn;
         float* vbuf[2] = {s->V, s->Vlog};   // carried state, double-buffered by round (Vlog is free on this path)
