@@ -1320,7 +1320,9 @@ static bool plan_round(dsat_session* s) {
                 s->p3_part = s->p2_split && !(ep != nullptr && ep[0] == '0') && F % 32 == 0 &&
                              s->hid_ld[DSAT_MLP_UPDATE_GATE] >= 16 * r.sp_nt[0] && r.sp_nt[0] <= ROUND_NWAVES &&
                              3 * 64 * (F + 16) * 2 <= LDS * 4;
-                if (s->p3_part && ep != nullptr && ep[0] == '2') s->p3_part = 2;   // also in the last wave of a multi-wave P2
+                // 2: also in the last wave of a multi-wave P2 (role_d_blocks only lets it when three groups per idle CU
+                // cover the batch -- config 5: 157 groups on 70 idle CUs; config 3 with its 16 idle CUs: no); 1: single wave only
+                if (s->p3_part) s->p3_part = (ep != nullptr && ep[0] == '1') ? 1 : 2;
             }
         }
         if (s->p3_bm == 32 && !s->p3_split) ok = false;   // the tables were built for 32-row producer tiles
@@ -1978,18 +1980,18 @@ static void plan_pair_blocks(int n_cus, int n_active, int* first, int* blocks, i
 // a workgroup 12-15 k cycles, a clause tile lasts ~52 k, select/SAT of a small graph ~28 k: the select workgroups
 // take groups too unless they are the long parts of a large graph (sel_lead > 0).
 static int role_d_blocks(const dsat_session* s, int actN, int actC, bool sel_on, int sel_lead, int n_sel, int* workers,
-                         int* dsel) {
+                         int* dsel, bool sel_work = true) {   // sel_work: the select workgroups take role-D groups too
     *workers = 0;
     *dsel = 0;
     if (!s->p3_part || s->prefer_tp || s->p2_rb != 4) return 0;
     const int p2_blocks = (actC + 63) / 64 + (sel_on ? (sel_lead > 0 ? sel_lead : n_sel) : 0);
     // CUs without a clause tile: all but the tiles' own in a single wave of workgroups, those of the LAST wave otherwise
-    // (the role-D blocks are the last of the grid, so that is where they land; DSAT_P3_PART=2 to allow it)
+    // (the role-D blocks are the last of the grid, so that is where they land; DSAT_P3_PART=1 confines role D to single waves)
     const int rem2 = p2_blocks % s->n_cus;
     const int nd = (actN + 63) / 64;
     const int free_cus = p2_blocks < s->n_cus ? s->n_cus - p2_blocks
                                               : (s->p3_part >= 2 && rem2 != 0 ? s->n_cus - rem2 : 0);
-    const int sel_workers = sel_on && sel_lead == 0 ? n_sel : 0;
+    const int sel_workers = sel_on && sel_lead == 0 && sel_work ? n_sel : 0;
     const int extra_blocks = std::min(std::max(nd - sel_workers, 1), std::max(free_cus, 0));
     if (free_cus < 8 || nd > 3 * extra_blocks + sel_workers) return 0;
     *workers = sel_workers + extra_blocks;
@@ -2104,11 +2106,12 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         a3.V = a1.V_out;                    // the state P1 of this round wrote
         {   // role D: only on CUs the clause tiles (and the select workgroups) leave idle
             int workers = 0, dsel = 0;
-            const int extra_blocks = role_d_blocks(s, actN, actC, a2.s_enable != 0, a2.sel_lead, a2.n_sel, &workers, &dsel);
+            const bool pack = s->sel_pack_on && a2.s_enable && a2.sel_lead == 0 && a2.n_sel >= 64 &&
+                              (actN + a2.n_sel - 1) / a2.n_sel <= 1024;
+            if (pack) a2.sel_pack = 4;   // (packed select workgroups are not role-D workers)
+            const int extra_blocks = role_d_blocks(s, actN, actC, a2.s_enable != 0, a2.sel_lead,
+                                                   pack ? (a2.n_sel + 3) / 4 : a2.n_sel, &workers, &dsel, !pack);
             const bool part = extra_blocks > 0;
-            if (!part && s->sel_pack_on && a2.s_enable && a2.sel_lead == 0 && a2.n_sel >= 64 &&
-                (actN + a2.n_sel - 1) / a2.n_sel <= 1024)
-                a2.sel_pack = 4;
             a2.d_blocks = extra_blocks;
             a2.d_sel = dsel;
             a2.d_workers = workers;
