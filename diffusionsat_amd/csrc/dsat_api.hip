@@ -840,6 +840,11 @@ struct dsat_session {
     std::vector<int32_t> h_pack_off;
     int32_t* pack_off = nullptr;
     int n_sel = 0, sel_zero = 0;
+    // a large graph's select parts split its KL sums and exchange the partials (select_sat_body, SHARE): only while
+    // the parts are certainly co-resident (one workgroup per CU in P2); DSAT_SEL_SHARE=0: every part sums everything
+    int sel_share = 0;
+    unsigned long long* sel_exch = nullptr;
+    int sel_ticks = SEL_EXCH_TICKS;   // DSAT_SEL_EXCH_TICKS (-1: the parts never see each other's words -- tests)
     long long* stamps = nullptr;   // [3][4096][8] when DSAT_STAMPS=1
     RoundArgs ra1, ra2, ra3;   // templates: per-launch fields (round, tail, ...) are patched in
     // graph replay
@@ -917,6 +922,7 @@ static void carve(dsat_session* s, Slab& sl) {
         s->psum2_c = sl.take<float>((size_t)s->n_cchunks * F);
     }
     s->sel_tab = sl.take<int32_t>(s->h_sel_tab.size());
+    if (s->sel_share) s->sel_exch = sl.take<unsigned long long>((size_t)s->n_sel * LOGIT_MAPS);
     s->vmeta4 = sl.take<int32_t>(s->h_vmeta4.size());
     s->pack_off = sl.take<int32_t>(s->h_pack_off.size());
     s->lid = sl.take<int32_t>(G); s->move_src = sl.take<int32_t>(G); s->n_act_dev = sl.take<int32_t>(4);
@@ -1082,6 +1088,7 @@ static bool plan_round(dsat_session* s) {
     a.vgseg2 = s->n_vchunks > 0 ? s->vgseg2 : nullptr; a.psum2_v = s->psum2_v;
     a.cgseg2 = s->n_cchunks > 0 ? s->cgseg2 : nullptr; a.psum2_c = s->psum2_c;
     a.sel_tab = s->sel_tab; a.n_sel = s->n_sel; a.sel_zero = s->sel_zero;
+    a.sel_exch = s->sel_exch; a.sel_ticks = s->sel_ticks;
     a.inv_f = 1.f / (float)w->layout.feature_maps; a.fm = w->layout.feature_maps;
     a.gj2_three = g->max_clause_len <= 3 && getenv("DSAT_GJ2_FOUR") == nullptr;
     a.vlist = s->vlist_stride > 0 ? s->vmeta4 + s->vlist_at : nullptr; a.vlist_stride = s->vlist_stride; a.vlist_max = s->vlist_max;
@@ -1421,6 +1428,9 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             }
         }
         s->n_sel = (int)(s->h_sel_tab.size() / 4);
+        s->sel_share = s->sel_zero && round_up(s->n_sel, 8) <= s->n_cus;
+        if (const char* ev = getenv("DSAT_SEL_SHARE")) s->sel_share = s->sel_share && atoi(ev) != 0;
+        if (const char* ev = getenv("DSAT_SEL_EXCH_TICKS")) s->sel_ticks = atoi(ev);
         s->h_pack_off.assign(g->G + 1, 0);
         for (int gi = 0; gi < g->G; ++gi)
             s->h_pack_off[gi + 1] = s->h_pack_off[gi] + (g->h_var_seg[gi + 1] - g->h_var_seg[gi] + 7) / 8;
@@ -2023,6 +2033,8 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
     int cn3_prev = 0;   // role-C blocks the previous round's P3 carried: the clause state is already normalised ...
     int cn3_rows = 0;   // ... for rows below this (0: all of them)
     // the non-state columns of v1 (normal draw, noisy_num, noise_scale, denoised) of all rounds
+    if (s->sel_exch != nullptr)   // the select parts' exchange words: an epoch (round + 1) is seen once per step
+        note(hipMemsetAsync(s->sel_exch, 0, (size_t)s->n_sel * LOGIT_MAPS * sizeof(unsigned long long), st));
     L.run(KC_MISC, [&] { launch_aux(s->aux, actN, rounds, s->in_noisy, s->ctl, st); });   // :214-219, :239
     for (int r = 0; r <= rounds; ++r) {
         a1.round = r;
@@ -2081,7 +2093,7 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
             // R15-R17 of the last round (with early exit the earlier rounds' run inside P2)
             L.run(KC_SELECT_SAT, [&] {
                 launch_select_sat(s->g, s->sel_tab, act_graphs >= 0 ? act_graphs : s->n_sel, s->logits, s->ctl, s->pgl, s->best, s->out_logits,
-                                  s->assign, s->graph_unsat, r - 1, early_exit, st);
+                                  s->assign, s->graph_unsat, r - 1, early_exit, s->sel_exch, s->sel_ticks, st);
             });
             break;
         }
@@ -2094,7 +2106,7 @@ static int enqueue_step_fused(dsat_session* s, hipStream_t st, int rounds, int e
         if (early_exit && r > 0 && s->unsupervised)   // supervised=False: the rule lives in the stand-alone kernel only
             L.run(KC_SELECT_SAT, [&] {
                 launch_select_sat(s->g, s->sel_tab, act_graphs >= 0 ? act_graphs : s->n_sel, s->logits, s->ctl, s->pgl, s->best,
-                                  s->out_logits, s->assign, s->graph_unsat, r - 1, early_exit, st);
+                                  s->out_logits, s->assign, s->graph_unsat, r - 1, early_exit, s->sel_exch, s->sel_ticks, st);
             });
         a2.cs_ready = cn > 0 || cn3_prev > 0;
         a2.cs_ready_rows = cn3_prev > 0 ? cn3_rows : 0;

@@ -357,6 +357,10 @@ struct RoundArgs {
     int cs_ready_rows;     // P2: clause rows below this were normalised by a role C before this launch (replaces the
                            //     all-or-nothing cs_ready for P3-hosted role C on large batches)
     int p3_tiles;          // P3: variable tiles of the launch (the grid also holds the role-C blocks)
+    // P2's select parts of a large graph (and the stand-alone select kernel): n_sel x LOGIT_MAPS words
+    // {epoch, partial KL sum}, zeroed by the host at the start of every step; nullptr: every part sums everything
+    unsigned long long* sel_exch;
+    int sel_ticks;         // bound on a part's wait for the others' words, 100 MHz ticks (< 0: never served -- tests)
 };
 constexpr int TILE_META_INTS = 16;
 constexpr int LIST_BLOCK_LOADS = 4;    // ints per thread with which a workgroup fetches a tile's list block
@@ -393,10 +397,12 @@ hipError_t launch_heavy_gather(const int2* pieces, int n_pieces, const int32_t* 
                                const float* vla, int C, float* hpart, const int* done, hipStream_t st);
 void launch_select_sat(const dsat_graph* g, const int32_t* sel_tab, int n_sel, const float* logits, Ctl* ctl,
                        float* pgl, int32_t* best, float* out_logits, uint8_t* assign, int32_t* graph_unsat,
-                       int round, int set_done, hipStream_t st);
+                       int round, int set_done, unsigned long long* sel_exch, int sel_ticks,
+                       hipStream_t st);
 constexpr int SEG2_MIN = 32;      // graphs with more PairNorm segments than this get level-2 sums
 constexpr int SEG2_CHUNK = 64;    // level-1 segments per level-2 sum
 constexpr int SEL_PART_CLAUSES = 4096;   // clauses per select/SAT workgroup of a large graph
+constexpr int SEL_EXCH_TICKS = 20000;   // bound on a select part's wait for the other parts' sums: 200 us of the 100 MHz clock
 hipError_t launch_segsum2(const int2* chunks, int n_chunks, const float* psum, float* psum2, const int* done,
                           hipStream_t st);
 

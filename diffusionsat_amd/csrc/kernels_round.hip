@@ -459,7 +459,7 @@ __device__ __forceinline__ void list_block_store(const ListBlock& lb, int* dst, 
 }
 
 // R15-R17 for one graph (forward declaration; defined with the stand-alone kernel below)
-template <int NTH, bool UNSUP = false>
+template <int NTH, bool UNSUP = false, bool SHARE = false>
 __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int32_t* __restrict__ sel_tab,
                                 const int32_t* __restrict__ vseg,
                                 const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
@@ -467,7 +467,8 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
                                 Ctl* __restrict__ ctl, float* __restrict__ pgl, int32_t* __restrict__ best,
                                 float* __restrict__ out_logits, uint8_t* __restrict__ assign,
                                 int32_t* __restrict__ graph_unsat, int N, int round, int set_done, float* sred,
-                                int tid = (int)threadIdx.x, bool active = true);
+                                int tid = (int)threadIdx.x, bool active = true,
+                                unsigned long long* sel_exch = nullptr, int sel_ticks = 0);
 
 // R10 for a contiguous range of clause rows (one of `nb` extra workgroups of P1): same arithmetic
 // as pairnorm_tile, streamed; clause_state is updated in place for P2 to load.
@@ -1257,6 +1258,9 @@ __device__ __forceinline__ void role_d(const RoundArgs& a, int blk, float* smem,
     }
 }
 
+// SHARE: the select parts of a large graph exchange their partial KL sums (select_sat_body); its own instantiation, so
+// that the kernel of the batches without such graphs keeps its code (and register allocation) as it was
+template <bool SHARE>
 __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_kernel(RoundArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     constexpr int RB = 4, BM = 16 * RB;
@@ -1304,9 +1308,9 @@ __global__ __launch_bounds__(NT, ROUND_WGS_PER_CU * NT / 256) void round_p2s_ker
                                  a.logits, a.ctl, a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, NL, a.round - 1,
                                  a.check_done, smem + sub * 2560, tid & 255, act);
         } else
-        select_sat_body<NT>(sel_blk, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits, a.ctl,
-                            a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, NL, a.round - 1, a.check_done,
-                            smem);
+        select_sat_body<NT, false, SHARE>(sel_blk, a.n_sel, a.sel_tab, a.var_seg, a.cl_seg, a.c_rowptr, a.c_lit, a.logits,
+                                          a.ctl, a.pgl, a.best, a.out_logits, a.assign, a.graph_unsat, NL, a.round - 1,
+                                          a.check_done, smem, tid, true, a.sel_exch, a.sel_ticks);
         DSAT_STAMP(a, 4);
         DSAT_STAMP_RT_END(a);
         if (a.d_sel != 0 && sel_blk < a.n_sel) {   // ... then this workgroup's share of role D
@@ -2100,7 +2104,7 @@ __device__ __forceinline__ float bern_kl(float a, float b) {
 // copies that ride in P2's grid stay as they were -- the extra code in front of P2's tile loops cost config 2 0.5 % (its
 // placement, not its execution: the branch is never taken there) -- and an unsupervised session launches the kernel
 // between P1 and P2 instead (dsat_api.hip).
-template <int NTH, bool UNSUP>
+template <int NTH, bool UNSUP, bool SHARE>
 __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int32_t* __restrict__ sel_tab,
                                 const int32_t* __restrict__ vseg,
                                 const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
@@ -2108,7 +2112,7 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
                                 Ctl* __restrict__ ctl, float* __restrict__ pgl, int32_t* __restrict__ best,
                                 float* __restrict__ out_logits, uint8_t* __restrict__ assign,
                                 int32_t* __restrict__ graph_unsat, int N, int round, int set_done, float* sred,
-                                int tid, bool active) {
+                                int tid, bool active, unsigned long long* sel_exch, int sel_ticks) {
     // sred: NTH*(LOGIT_MAPS+1) + 2 floats of LDS.  tid / active: several entries may share a workgroup (P2's packed
     // select blocks: NTH threads each, tid = the thread's index within its entry, every barrier below is taken by all
     // of them together -- entries with parts == 1 only); an inactive sub-block mirrors a valid entry's control flow
@@ -2130,7 +2134,21 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
         if (unsup)   // supervised=False: the graph's own clause loss per logit map (every part recomputes all of it)
             for (int c = cseg[g] + tid; c < cseg[g + 1]; c += NTH) unsup_clause_loss8(logits, rowptr, c_lit, c, N, acc);
     }
-    for (int v = v0 + tid; v < v1 && !unsup; v += NTH) {
+    // SHARE (a graph of several parts, the parts co-resident): each part sums the KL terms of its own slice of the
+    // variables and the parts exchange their eight partial sums (below) instead of each summing all of them -- at
+    // config 5 (10 000 variables, 15 parts) the redundant sums were the whole duration of P2 (r03 stamps).
+    int kv0 = v0, kv1 = v1;
+    bool share = false;
+    if constexpr (SHARE) {
+        share = sel_exch != nullptr && parts > 1 && !unsup;
+        if (share) {
+            const int per = (v1 - v0 + parts - 1) / parts;
+            kv0 = min(v0 + part * per, v1);
+            kv1 = min(kv0 + per, v1);
+        }
+    }
+    auto kl_terms = [&](int lo, int hi) {
+    for (int v = lo + tid; v < hi && !unsup; v += NTH) {
         int label;
         if (ctl->inj_labels != nullptr) {
             label = ctl->inj_labels[ctl->labels_step_stride * ctl->step + logical_var(ctl, v)];
@@ -2149,6 +2167,8 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
             acc[k] += (a * (log_a - logf(b)) + (1.f - a) * (log_1ma - log1pf(-b))) / norm;
         }
     }
+    };
+    auto tree_sum = [&]() {   // red[0][k] = the sum over the workgroup's threads of acc[k]
 #pragma unroll
     for (int k = 0; k < LOGIT_MAPS; ++k) red[tid][k] = acc[k];
     if (tid == 0) *s_unsat = 0;
@@ -2159,6 +2179,67 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
             for (int k = 0; k < LOGIT_MAPS; ++k) red[tid][k] += red[tid + s][k];
         }
         __syncthreads();
+    }
+    };
+    kl_terms(kv0, kv1);
+    tree_sum();
+    if constexpr (SHARE) {
+        if (share) {
+            // One 64-bit word per (part, map): {epoch = round + 1, the partial sum's bits}, stored and polled with
+            // agent-scope atomics (write-through to the memory side, no fence: the word is its own flag).  The host
+            // zeroes the words at the start of every denoising step, so an epoch is seen once.  Every part adds the
+            // partials in part order: all of them pick the same map.  A part that is not served within the bound
+            // (parts not co-resident: more parts than CUs) forms every slice's sum itself, slice by slice with the same
+            // thread-to-variable assignment and the same tree -- bit for bit the exchanged result.
+            const int base = blk - part;
+            const unsigned epoch = (unsigned)(round + 1);
+            if (tid < LOGIT_MAPS)
+                __hip_atomic_store(sel_exch + (size_t)blk * LOGIT_MAPS + tid,
+                                   ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(red[0][tid]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int ok = 1;
+            if (tid == 0) *s_best = 1;   // "every word arrived", cleared by a thread whose word did not
+            __syncthreads();
+            const long long t0 = wall_clock64();
+            for (int i = tid; i < parts * LOGIT_MAPS; i += NTH) {
+                const unsigned long long* w = sel_exch + (size_t)base * LOGIT_MAPS + i;
+                unsigned long long x;
+                for (;;) {
+                    x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (sel_ticks < 0) { ok = 0; break; }   // tests: the unserved part's path
+                    if ((unsigned)(x >> 32) == epoch) break;
+                    if (wall_clock64() - t0 > sel_ticks) { ok = 0; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                red[1 + (i >> 3)][i & 7] = __uint_as_float((unsigned)x);
+            }
+            if (!ok) *s_best = 0;
+            __syncthreads();
+            ok = *s_best;
+            if (ok) {
+                if (tid < LOGIT_MAPS) {
+                    float sum = 0.f;
+                    for (int p = 0; p < parts; ++p) sum += red[1 + p][tid];
+                    red[0][tid] = sum;
+                }
+                __syncthreads();
+            } else {
+                float tot = 0.f;   // threads 0 .. 7: one map each
+                const int per = (v1 - v0 + parts - 1) / parts;
+                for (int p = 0; p < parts; ++p) {
+#pragma unroll
+                    for (int k = 0; k < LOGIT_MAPS; ++k) acc[k] = 0.f;
+                    const int lo = min(v0 + p * per, v1);
+                    __syncthreads();   // red[0] of the slice before is read
+                    kl_terms(lo, min(lo + per, v1));
+                    tree_sum();
+                    if (tid < LOGIT_MAPS) tot += red[0][tid];
+                }
+                __syncthreads();
+                if (tid < LOGIT_MAPS) red[0][tid] = tot;
+                __syncthreads();
+            }
+        }
     }
     if (tid == 0) {
         const float inv = 1.f / (float)(v1 - v0);
@@ -2233,11 +2314,13 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
     const int32_t* __restrict__ vseg, const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ c_lit, const float* __restrict__ logits, Ctl* __restrict__ ctl,
     float* __restrict__ pgl, int32_t* __restrict__ best, float* __restrict__ out_logits,
-    uint8_t* __restrict__ assign, int32_t* __restrict__ graph_unsat, int N, int round, int set_done) {
+    uint8_t* __restrict__ assign, int32_t* __restrict__ graph_unsat, int N, int round, int set_done,
+    unsigned long long* sel_exch, int sel_ticks) {
     if (set_done && ctl->done != 0) return;
     __shared__ float sred[256 * (LOGIT_MAPS + 1) + 2];
-    select_sat_body<256, true>(blockIdx.x, gridDim.x, sel_tab, vseg, cseg, rowptr, c_lit, logits, ctl, pgl, best, out_logits,
-                         assign, graph_unsat, N, round, set_done, sred);
+    select_sat_body<256, true, true>(blockIdx.x, gridDim.x, sel_tab, vseg, cseg, rowptr, c_lit, logits, ctl, pgl, best,
+                                     out_logits, assign, graph_unsat, N, round, set_done, sred, (int)threadIdx.x, true,
+                                     sel_exch, sel_ticks);
 }
 
 }  // namespace
@@ -2258,7 +2341,10 @@ hipError_t launch_round_p2(const RoundArgs& a, int rb, hipStream_t st) {
     if (tiles == 0) return hipSuccess;
 #if DSAT_ROUND_NWAVES == 16
     if (rb == 4 && a.sp_ws[0] != nullptr) {
-        hipLaunchKernelGGL(round_p2s_kernel, dim3(tiles + a.d_blocks), dim3(NT), 0, st, a);
+        if (a.sel_exch != nullptr && a.s_enable && a.sel_lead > 0)
+            hipLaunchKernelGGL(round_p2s_kernel<true>, dim3(tiles + a.d_blocks), dim3(NT), 0, st, a);
+        else
+            hipLaunchKernelGGL(round_p2s_kernel<false>, dim3(tiles + a.d_blocks), dim3(NT), 0, st, a);
         return hipGetLastError();
     }
 #endif
@@ -2305,9 +2391,10 @@ hipError_t launch_heavy_gather(const int2* pieces, int n_pieces, const int32_t* 
 }
 void launch_select_sat(const dsat_graph* g, const int32_t* sel_tab, int n_sel, const float* logits, Ctl* ctl,
                        float* pgl, int32_t* best, float* out_logits, uint8_t* assign, int32_t* graph_unsat,
-                       int round, int set_done, hipStream_t st) {
+                       int round, int set_done, unsigned long long* sel_exch, int sel_ticks, hipStream_t st) {
     hipLaunchKernelGGL(select_sat_kernel, dim3(n_sel), dim3(256), 0, st, sel_tab, g->var_seg, g->cl_seg, g->c_rowptr,
-                       g->c_lit, logits, ctl, pgl, best, out_logits, assign, graph_unsat, g->N, round, set_done);
+                       g->c_lit, logits, ctl, pgl, best, out_logits, assign, graph_unsat, g->N, round, set_done, sel_exch,
+                       sel_ticks);
 }
 
 }  // namespace dsat

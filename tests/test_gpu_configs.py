@@ -293,6 +293,48 @@ def test_large_graph_select_parts_and_early_exit(rt):
             _host_check(batch, smp["assignment"].cpu().numpy(), smp["solved"].cpu().numpy() > 0)
 
 
+def test_select_parts_share_their_kl_sums(rt, monkeypatch):
+    """A graph of several select/SAT parts (3 000 variables, 20 000 clauses: five parts): the parts sum the KL terms of
+    a slice of the variables each and exchange the partial sums (select_sat_body, SHARE).  The map they pick is the
+    oracle's; a part that is never served (DSAT_SEL_EXCH_TICKS=-1) re-forms every slice's sum itself and gets bit for
+    bit the exchanged result; without the exchange (DSAT_SEL_SHARE=0: every part sums everything, the round-2 form)
+    the choice is the same.  Early exit on: the parts ride in P2 for rounds 0 .. R-2 and run in the stand-alone kernel
+    for the last one; eager and graph replay."""
+    from diffusionsat_amd.batch import make_batch
+    from diffusionsat_amd.instances import irregular_cnf
+    insts = [irregular_cnf(3000, 20000, seed=4, zipf_a=1.1)[:2]]
+    batch = make_batch(insts)
+    data = O.create_adj_matrices(insts)
+    ws = oracle_weights(5)
+    rounds = 6
+    d = draws(batch.n_vars, rounds, seed=12)
+    noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, np.float32), d["uniform"])
+    ref = O.diffusion_step(ws, data, np.float32(0.4), noisy, d["normal"], d["labels"], rounds, early_exit=True,
+                           dt=np.float32, trace=("per_graph_loss",))
+    srt = np.sort(ref["trace"]["per_graph_loss"][-1], axis=1)[0]
+    assert srt[1] - srt[0] > 1e-3                      # a clear winner: the choice is not a matter of rounding
+    g, w = rt.Graph(batch), rt.Weights(ws)
+    outs = {}
+    for name, env in (("share", {}), ("unserved", {"DSAT_SEL_EXCH_TICKS": "-1"}), ("redundant", {"DSAT_SEL_SHARE": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = rt.Session(g, w, max_rounds=rounds)
+        for k in env:
+            monkeypatch.delenv(k)
+        for replay in (False, True):
+            s.set_graph_replay(replay)
+            out = s.diffusion_step(0.4, _dev(noisy), _dev(d["normal"]), _dev(d["labels"]), rounds=rounds,
+                                   early_exit=True, want_logits=True)
+            assert int(out["steps_taken"].item()) == int(ref["steps_taken"])
+            assert np.array_equal(out["best_map"].cpu().numpy(), ref["best_map"]), (name, replay)
+            assert np.abs(out["prediction"].cpu().numpy() - ref["prediction"]).max() < 5e-4, (name, replay)
+            outs[(name, replay)] = out
+    for replay in (False, True):
+        for k in ("prediction", "logits", "best_map"):
+            assert torch.equal(outs[("share", replay)][k], outs[("unserved", replay)][k]), (k, replay)
+            assert torch.equal(outs[("share", replay)][k], outs[("redundant", replay)][k]), (k, replay)
+
+
 # ------------------------------------------------------------------------------------------ N1: early retirement
 def _easy_formula(n=16, m=64, k=6, seed=3):
     rng = np.random.default_rng(seed)
