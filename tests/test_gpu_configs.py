@@ -302,7 +302,10 @@ def test_select_parts_share_their_kl_sums(rt, monkeypatch):
     for the last one; eager and graph replay."""
     from diffusionsat_amd.batch import make_batch
     from diffusionsat_amd.instances import irregular_cnf
-    insts = [irregular_cnf(3000, 20000, seed=4, zipf_a=1.1)[:2]]
+    # two such graphs with small ones before, between and behind them: a part finds its peers at blk - part
+    small = [irregular_cnf(40, 160, seed=20 + i, zipf_a=1.3)[:2] for i in range(3)]
+    insts = [small[0], irregular_cnf(3000, 20000, seed=4, zipf_a=1.1)[:2], small[1],
+             irregular_cnf(2000, 9000, seed=6, zipf_a=1.2)[:2], small[2]]
     batch = make_batch(insts)
     data = O.create_adj_matrices(insts)
     ws = oracle_weights(5)
@@ -311,8 +314,8 @@ def test_select_parts_share_their_kl_sums(rt, monkeypatch):
     noisy = O.randomized_rounding(np.full((batch.n_vars, 2), 0.5, np.float32), d["uniform"])
     ref = O.diffusion_step(ws, data, np.float32(0.4), noisy, d["normal"], d["labels"], rounds, early_exit=True,
                            dt=np.float32, trace=("per_graph_loss",))
-    srt = np.sort(ref["trace"]["per_graph_loss"][-1], axis=1)[0]
-    assert srt[1] - srt[0] > 1e-3                      # a clear winner: the choice is not a matter of rounding
+    srt = np.sort(ref["trace"]["per_graph_loss"][-1], axis=1)
+    assert (srt[:, 1] - srt[:, 0]).min() > 1e-4        # clear winners: the choice is not a matter of rounding
     g, w = rt.Graph(batch), rt.Weights(ws)
     outs = {}
     for name, env in (("share", {}), ("unserved", {"DSAT_SEL_EXCH_TICKS": "-1"}), ("redundant", {"DSAT_SEL_SHARE": "0"})):
