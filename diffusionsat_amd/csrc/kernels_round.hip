@@ -2309,7 +2309,14 @@ __device__ __forceinline__ void select_sat_body(int blk, int nblocks, const int3
     }
 }
 
-__global__ __launch_bounds__(256) void select_sat_kernel(
+// The stand-alone form (the last round of a step; every round of a supervised=False session): the loops over a graph's
+// variables and clauses are chains of dependent loads (record -> list -> logits), so the threads are what hides them:
+// 1024 per graph or part, as the copies that ride in P2 (with 256: 14.2 -> 13.7 us at config 2, 76 -> 37 us at config 5)
+#ifndef DSAT_SEL_NTH
+#define DSAT_SEL_NTH 1024
+#endif
+constexpr int SEL_NTH = DSAT_SEL_NTH;
+__global__ __launch_bounds__(SEL_NTH) void select_sat_kernel(
     const int32_t* __restrict__ sel_tab,
     const int32_t* __restrict__ vseg, const int32_t* __restrict__ cseg, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ c_lit, const float* __restrict__ logits, Ctl* __restrict__ ctl,
@@ -2317,8 +2324,8 @@ __global__ __launch_bounds__(256) void select_sat_kernel(
     uint8_t* __restrict__ assign, int32_t* __restrict__ graph_unsat, int N, int round, int set_done,
     unsigned long long* sel_exch, int sel_ticks) {
     if (set_done && ctl->done != 0) return;
-    __shared__ float sred[256 * (LOGIT_MAPS + 1) + 2];
-    select_sat_body<256, true, true>(blockIdx.x, gridDim.x, sel_tab, vseg, cseg, rowptr, c_lit, logits, ctl, pgl, best,
+    __shared__ float sred[SEL_NTH * (LOGIT_MAPS + 1) + 2];
+    select_sat_body<SEL_NTH, true, true>(blockIdx.x, gridDim.x, sel_tab, vseg, cseg, rowptr, c_lit, logits, ctl, pgl, best,
                                      out_logits, assign, graph_unsat, N, round, set_done, sred, (int)threadIdx.x, true,
                                      sel_exch, sel_ticks);
 }
@@ -2392,7 +2399,7 @@ hipError_t launch_heavy_gather(const int2* pieces, int n_pieces, const int32_t* 
 void launch_select_sat(const dsat_graph* g, const int32_t* sel_tab, int n_sel, const float* logits, Ctl* ctl,
                        float* pgl, int32_t* best, float* out_logits, uint8_t* assign, int32_t* graph_unsat,
                        int round, int set_done, unsigned long long* sel_exch, int sel_ticks, hipStream_t st) {
-    hipLaunchKernelGGL(select_sat_kernel, dim3(n_sel), dim3(256), 0, st, sel_tab, g->var_seg, g->cl_seg, g->c_rowptr,
+    hipLaunchKernelGGL(select_sat_kernel, dim3(n_sel), dim3(SEL_NTH), 0, st, sel_tab, g->var_seg, g->cl_seg, g->c_rowptr,
                        g->c_lit, logits, ctl, pgl, best, out_logits, assign, graph_unsat, g->N, round, set_done, sel_exch,
                        sel_ticks);
 }
