@@ -1436,7 +1436,13 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             s->h_pack_off[gi + 1] = s->h_pack_off[gi] + (g->h_var_seg[gi + 1] - g->h_var_seg[gi] + 7) / 8;
         // heavy literal rows: a "light" copy of the literal->clause CSR with those rows emptied, the
         // pieces heavy_gather_kernel sums, and per literal row where its pieces are
-        if (const char* ev = getenv("DSAT_HEAVY_T")) s->heavy_t = std::max(1, atoi(ev));
+        // Two thresholds: a graph with a literal row above heavy_t gets the heavy path at all (a launch per round);
+        // once it has it, every row above heavy_row goes through it -- a tile's walk over a row's clauses is a chain of
+        // dependent loads, the streaming kernel is not: config 5, rows above 32 / 16 / 8: 108.6 / 110.0 / 110.0 steps/s
+        // (P3 64.9 / 58.9 / 53.0 us, the heavy launch growing by as much below 16).  DSAT_HEAVY_T sets both.
+        int heavy_row = std::min(s->heavy_t, HEAVY_ROW_MIN);
+        if (const char* ev = getenv("DSAT_HEAVY_T")) s->heavy_t = heavy_row = std::max(1, atoi(ev));
+        if (const char* ev = getenv("DSAT_HEAVY_ROW")) heavy_row = std::max(1, std::min(s->heavy_t, atoi(ev)));
         const int32_t* lrp = g->h_l_rowptr.data();
         if (g->max_lit_deg > s->heavy_t) {
             const size_t rows = 2 * (size_t)g->N;
@@ -1444,7 +1450,7 @@ static int session_create_impl(dsat_arena* arena, hipStream_t st, const dsat_gra
             s->h_lhv.assign(2 * rows, 0);
             for (size_t i = 0; i < rows; ++i) {
                 const int deg = lrp[i + 1] - lrp[i];
-                if (deg > s->heavy_t) {
+                if (deg > heavy_row) {
                     const int np = (deg + HEAVY_PIECE - 1) / HEAVY_PIECE;
                     s->h_lhv[2 * i] = (int32_t)(s->h_pieces.size() / 2);
                     s->h_lhv[2 * i + 1] = np;

@@ -392,6 +392,7 @@ hipError_t launch_round_p3(const RoundArgs& a, hipStream_t st);
 // HEAVY_PIECE entries, each summed by one workgroup of heavy_gather_kernel (spread over the whole
 // chip) instead of serially by the one half-wave that owns the row in its P3 tile.
 constexpr int HEAVY_ROW_T = 32;
+constexpr int HEAVY_ROW_MIN = 16;   // ... and once a graph has such a row, every row above this takes the heavy path (dsat_api.hip)
 constexpr int HEAVY_PIECE = 512;
 hipError_t launch_heavy_gather(const int2* pieces, int n_pieces, const int32_t* l_clause, const float* closs4,
                                const float* vla, int C, float* hpart, const int* done, hipStream_t st);
