@@ -701,6 +701,9 @@ __device__ __forceinline__ void role_a2(const RoundArgs& a, int tile, const Tile
 // kernel).  Used when role B covers every row of the batch (the tile then is PairNorm + lit_mlp only) and
 // role A is not on 32-row tiles.  LDS: h1 [3][16][528] (first the fp32 PairNorm rows) | h2 [3][16][528] | v1 planes
 // [3][16][176] | mean: 116 KB.
+#ifndef DSAT_A1_ONE_RING
+#define DSAT_A1_ONE_RING 1
+#endif
 __device__ __forceinline__ void role_a1s(const RoundArgs& a, int tile, const TileMetaDev& tm, float* smem, int tid) {
     constexpr int BM = 16, PD = DSAT_SPLIT_PD_A1;
     constexpr int KS0 = (F + AUX_W + 31) / 32, LDX = KS0 * 32 + 16, HID = 512, LD1 = HID + 16;
@@ -753,6 +756,26 @@ __device__ __forceinline__ void role_a1s(const RoundArgs& a, int tile, const Til
     f32x4 a0a[1] = {z}, a0b[1] = {z}, a1a[1] = {z}, a1b[1] = {z}, a2[1] = {z};
     // L0 and L1: column tiles wv, then wv + 16; the first barrier also ends the reads of the fp32 rows h1 is about
     // to overwrite
+#if DSAT_A1_ONE_RING
+    // one ring across the five passes (split_vpass): the next pass's first fragments travel during this one's last steps
+    static_assert(KS0 >= PD && KS1 >= PD && KS2 >= PD, "a pass is at least one turn of the ring");
+    const float4* const pw[5] = {wb(0, wv, KS0), wb(0, wv + 16, KS0), wb(1, wv, KS1), wb(1, wv + 16, KS1), wb(2, wv, KS2)};
+    SplitSlot ring[PD];
+    split_vprime<PD>(ring, voff, pw[0]);
+    lds_barrier();   // v1's planes are published; also ends the reads of the fp32 rows h1 is about to overwrite
+    split_vpass<1, PD>(ring, voff, pw[0], 0, KS0, pw[1], xin, BM * LDX, LDX, a0a);
+    split_vpass<1, PD>(ring, voff, pw[1], KS0, KS0, pw[2], xin, BM * LDX, LDX, a0b);
+    split_st4(h1, BM * LD1, row * LD1 + wv * 16 + col4, leaky(a0a[0], b0a));
+    split_st4(h1, BM * LD1, row * LD1 + (wv + 16) * 16 + col4, leaky(a0b[0], b0b));
+    lds_barrier();
+    split_vpass<1, PD>(ring, voff, pw[2], 2 * KS0, KS1, pw[3], h1in, BM * LD1, LD1, a1a);
+    split_vpass<1, PD>(ring, voff, pw[3], 2 * KS0 + KS1, KS1, pw[4], h1in, BM * LD1, LD1, a1b);
+    split_st4(h2, BM * LD1, row * LD1 + wv * 16 + col4, leaky(a1a[0], b1a));
+    split_st4(h2, BM * LD1, row * LD1 + (wv + 16) * 16 + col4, leaky(a1b[0], b1b));
+    lds_barrier();
+    split_vpass<1, PD>(ring, voff, pw[4], 2 * KS0 + 2 * KS1, KS2, pw[4] + (size_t)(KS2 - PD) * 192, h2in, BM * LD1, LD1, a2);
+    split_vdrain<PD>(ring);
+#else
     split_layer<1, PD>(voff, wb(0, wv, KS0), KS0, xin, BM * LDX, LDX, [] {}, a0a);
     split_layer<1, PD, false>(voff, wb(0, wv + 16, KS0), KS0, xin, BM * LDX, LDX, [] {}, a0b);
     auto ep0 = [&]() {
@@ -766,6 +789,7 @@ __device__ __forceinline__ void role_a1s(const RoundArgs& a, int tile, const Til
         split_st4(h2, BM * LD1, row * LD1 + (wv + 16) * 16 + col4, leaky(a1b[0], b1b));
     };
     split_layer<1, PD>(voff, wb(2, wv, KS2), KS2, h2in, BM * LD1, LD1, ep1, a2);
+#endif
     // R6: literals = [lit_mlp(v1)[:, :128] ; [:, 128:]]
     float* lits = a.lits;
     const int col = wv * 16 + col4;

@@ -250,6 +250,64 @@ __device__ __forceinline__ void split_layer(unsigned voff, const float4* __restr
     }
 }
 
+// ONE ring across the passes of a chain (role A of P1: five passes -- two column tiles in each of lit_mlp's 512-wide
+// layers, one in the last -- that used to prime, run and drain a ring each).  The wave's fragments form one stream: a pass
+// covers the virtual steps [B, B + ks), slot V % PD holds step V, and when step V has been consumed its slot asks for
+// step V + PD, which may already belong to the NEXT pass (weights do not depend on activations): no refills clamped to
+// the pass's last step (PD per pass: a quarter of the stream of a 16-row tile, which is bound by exactly that stream,
+// 64 B/clk/CU: tools/l2_stream_probe.hip), no empty pipe when the next pass starts.  `wnext`: the next pass's fragments;
+// for the chain's last pass its own last PD steps again, so that every wait has 3 * (PD - 1) younger loads behind the
+// slot it releases.  The first turn of a pass may start inside the ring and the last may end inside it: the steps
+// outside [B, B + ks) are skipped (a uniform branch).  tools/lit16w_probe.hip, mode 3: 57.4 k -> 52.6 k cycles.
+template <int PD>
+__device__ __forceinline__ void split_vprime(SplitSlot (&ring)[PD], unsigned voff, const float4* __restrict__ wbase) {
+    static_assert(3 * PD <= 63, "vmcnt field is 6 bits");
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+        gload_b128(ring[p].h, voff, wbase + (size_t)p * 192);
+        gload_b128(ring[p].m, voff, wbase + (size_t)p * 192 + 64);
+        gload_b128(ring[p].l, voff, wbase + (size_t)p * 192 + 128);
+    }
+}
+template <int NRB, int PD>
+__device__ __forceinline__ void split_vpass(SplitSlot (&ring)[PD], unsigned voff, const float4* __restrict__ wb, int B, int ks,
+                                            const float4* __restrict__ wnext, const unsigned short* px, int plane, int ld,
+                                            sf32x4 (&acc)[NRB]) {
+    const int E = B + ks;
+    for (int c = B / PD * PD; c < E; c += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            const int V = c + p;
+            if (V >= B && V < E) {
+                const unsigned short* q = px + (V - B) * 32;
+                split_rotate_prio(V - B);
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q), xm = *reinterpret_cast<const bf16x8*>(q + plane),
+                             xl = *reinterpret_cast<const bf16x8*>(q + 2 * plane);
+                // slot p was requested PD steps ago; 3 * (PD - 1) younger loads may stay in flight
+                asm volatile("s_waitcnt vmcnt(%3)" : "+v"(ring[p].h), "+v"(ring[p].m), "+v"(ring[p].l) : "n"(3 * (PD - 1)) : "memory");
+                split_step<NRB>(ring[p], xh, xm, xl, q, plane, ld, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                const int Vn = V + PD;
+                const float4* sb = Vn < E ? wb + (size_t)(Vn - B) * 192 : wnext + (size_t)(Vn - E) * 192;
+                gload_b128(ring[p].h, voff, sb);
+                gload_b128(ring[p].m, voff, sb + 64);
+                gload_b128(ring[p].l, voff, sb + 128);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+// After the chain's last pass: the refills past its end land before their registers are given to anything else.
+template <int PD>
+__device__ __forceinline__ void split_vdrain(SplitSlot (&ring)[PD]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0].h), "+v"(ring[0].m), "+v"(ring[0].l) :: "memory");
+#pragma unroll
+    for (int p = 1; p < PD; ++p) asm volatile("" : "+v"(ring[p].h), "+v"(ring[p].m), "+v"(ring[p].l));
+#ifndef DSAT_SPLIT_NO_ROTPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // Two consecutive columns (8 bytes of fp32) -> the three planes (4-byte stores); `off` a multiple of 2.
 __device__ __forceinline__ void split_st2(unsigned short* planes, int plane, int off, float2 v) {
     unsigned h, m, l;

@@ -177,10 +177,18 @@ __device__ __forceinline__ void pl_layer(unsigned voff, const float4* const (&wb
             split_rotate_prio(s + p);
             const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q), xm = *reinterpret_cast<const bf16x8*>(q + plane),
                          xl = *reinterpret_cast<const bf16x8*>(q + 2 * plane);
+#ifdef NO_REDUNDANT
+            if (s + p + PD > last + PD - 1 + 0 && false) {}
+            if (s + p > last - PD) TieP<NT>::template wait<0>(ring[p]);   // the layer's last PD steps: nothing younger is
+            else                                                           // guaranteed in flight (over-waits: probe only)
+#endif
             TieP<NT>::template wait<3 * NT * (PD - 1)>(ring[p]);
             pl_mfma<NT>(ring[p], xh, xm, xl, acc);
             __builtin_amdgcn_sched_barrier(0);
             const int sn = s + p + PD;
+#ifdef NO_REDUNDANT
+            if (sn <= last)
+#endif
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const float4* sb = wb[j] + (size_t)(sn < last ? sn : last) * 192;
@@ -212,6 +220,51 @@ __device__ __forceinline__ float4 leaky(sf32x4 acc, float4 b) {
     float4 v = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
     v.x = fmaxf(v.x, 0.2f * v.x); v.y = fmaxf(v.y, 0.2f * v.y); v.z = fmaxf(v.z, 0.2f * v.z); v.w = fmaxf(v.w, 0.2f * v.w);
     return v;
+}
+
+
+// MODE 3: ONE ring for the whole chain.  The wave's fragments form one stream: pass i (a layer's column tile) covers
+// virtual steps [B, B + ks); slot = V % PD; after step V is consumed the slot asks for step V + PD, which may already
+// belong to the next pass (weights do not depend on activations) -- no redundant refills at the end of a pass, no
+// empty pipe at the start of the next.  `wnext`: the next pass's fragments (the chain's last pass: its own last PD steps).
+#ifndef PDV
+#define PDV 3
+#endif
+template <int PD>
+__device__ __forceinline__ void vpass(SplitSlot (&ring)[PD], unsigned voff, const float4* wb, int B, int ks, const float4* wnext,
+                                      const unsigned short* px, int plane, int ld, sf32x4 (&acc)[1]) {
+    const int E = B + ks;
+    for (int c = B / PD * PD; c < E; c += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            const int V = c + p;
+            if (V >= B && V < E) {
+                const int k = V - B;
+                const unsigned short* q = px + k * 32;
+                split_rotate_prio(k);
+#ifdef X_NO_LDS
+                bf16x8 xh = __builtin_bit_cast(bf16x8, ring[(p + 1) % PD].h), xm = xh, xl = xh; (void)q;
+                asm volatile("" : "+v"(xh));
+#else
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q), xm = *reinterpret_cast<const bf16x8*>(q + plane),
+                             xl = *reinterpret_cast<const bf16x8*>(q + 2 * plane);
+#endif
+                asm volatile("s_waitcnt vmcnt(%3)" : "+v"(ring[p].h), "+v"(ring[p].m), "+v"(ring[p].l) : "n"(3 * (PD - 1)) : "memory");
+#ifdef X_NO_MFMA
+                acc[0][0] += ring[p].h[0] + ring[p].m[1] + ring[p].l[2] + __builtin_bit_cast(sf32x4, xh)[0] + __builtin_bit_cast(sf32x4, xm)[1] + __builtin_bit_cast(sf32x4, xl)[2];
+#else
+                split_step<1>(ring[p], xh, xm, xl, q, plane, ld, acc);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                const int Vn = V + PD;
+                const float4* sb = Vn < E ? wb + (size_t)(Vn - B) * 192 : wnext + (size_t)(Vn - E) * 192;
+                gload_b128(ring[p].h, voff, sb);
+                gload_b128(ring[p].m, voff, sb + 64);
+                gload_b128(ring[p].l, voff, sb + 128);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
 }
 
 template <int MODE>
@@ -257,6 +310,32 @@ __global__ __launch_bounds__(NTH) void kern(Args a) {
         };
         const float4* const w2[1] = {wb(a.w2, wv, KS2)};
         wf_layer<1, PDW + 1>(voff, w2, KS2, h2in, ROWS * LD1, ep1, a2);
+    } else if constexpr (MODE == 3) {
+        auto wb = [&](const float4* w, int tile, int ks) { return w + ((size_t)tile * ks * 3) * 64; };
+        const float4* const base[5] = {wb(a.w0, wv, KS0), wb(a.w0, wv + 16, KS0), wb(a.w1, wv, KS1), wb(a.w1, wv + 16, KS1), wb(a.w2, wv, KS2)};
+        sf32x4 t0a[1] = {z}, t0b[1] = {z}, t1a[1] = {z}, t1b[1] = {z};
+        SplitSlot ring[PDV];
+#pragma unroll
+        for (int p = 0; p < PDV; ++p) {
+            gload_b128(ring[p].h, voff, base[0] + (size_t)p * 192);
+            gload_b128(ring[p].m, voff, base[0] + (size_t)p * 192 + 64);
+            gload_b128(ring[p].l, voff, base[0] + (size_t)p * 192 + 128);
+        }
+        vpass<PDV>(ring, voff, base[0], 0, KS0, base[1], xin, ROWS * LDX, LDX, t0a);
+        vpass<PDV>(ring, voff, base[1], KS0, KS0, base[2], xin, ROWS * LDX, LDX, t0b);
+        split_st4(h1, ROWS * LD1, row * LD1 + wv * 16 + col4, leaky(t0a[0], b0a));
+        split_st4(h1, ROWS * LD1, row * LD1 + (wv + 16) * 16 + col4, leaky(t0b[0], b0b));
+        lds_barrier();
+        vpass<PDV>(ring, voff, base[2], 2 * KS0, KS1, base[3], h1in, ROWS * LD1, LD1, t1a);
+        vpass<PDV>(ring, voff, base[3], 2 * KS0 + KS1, KS1, base[4], h1in, ROWS * LD1, LD1, t1b);
+        split_st4(h2, ROWS * LD1, row * LD1 + wv * 16 + col4, leaky(t1a[0], b1a));
+        split_st4(h2, ROWS * LD1, row * LD1 + (wv + 16) * 16 + col4, leaky(t1b[0], b1b));
+        lds_barrier();
+        vpass<PDV>(ring, voff, base[4], 2 * KS0 + 2 * KS1, KS2, base[4] + (size_t)(KS2 - PDV) * 192, h2in, ROWS * LD1, LD1, a2);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0].h), "+v"(ring[0].m), "+v"(ring[0].l) :: "memory");
+#pragma unroll
+        for (int p = 1; p < PDV; ++p) asm volatile("" : "+v"(ring[p].h), "+v"(ring[p].m), "+v"(ring[p].l));
+        __builtin_amdgcn_s_setprio(0);
     } else if constexpr (MODE == 2) {
         auto wb = [&](const float4* w, int tile, int ks) { return w + ((size_t)tile * ks * 3) * 64; };
         const float4* const w0[2] = {wb(a.w0, wv, KS0), wb(a.w0, wv + 16, KS0)};
@@ -368,7 +447,7 @@ static int run(int blocks, const std::vector<float>& X, const std::vector<float>
     double emax = 0;
     for (size_t i = 0; i < out.size(); ++i) emax = std::max(emax, std::fabs(out[i] - ref[i]));
     printf("mode %d (%s) blocks %d: %lld cycles per 16-row tile (median; max %lld), kernel %.1f us; weights %.2f MB per tile; max |err| %.2e (|out| max %.2f)\n",
-           MODE, MODE == 1 ? "fp32 weights sliced in registers" : MODE == 2 ? "pre-sliced planes, two tiles per wave" : "pre-sliced planes", blocks, wg[blocks / 2], wg.back(), ms * 1e3, bytes / 1e6, emax, scale);
+           MODE, MODE == 1 ? "fp32 weights sliced in registers" : MODE == 2 ? "pre-sliced planes, two tiles per wave" : MODE == 3 ? "pre-sliced planes, one ring across the passes" : "pre-sliced planes", blocks, wg[blocks / 2], wg.back(), ms * 1e3, bytes / 1e6, emax, scale);
     return 0;
 }
 
@@ -391,5 +470,6 @@ int main(int argc, char** argv) {
     if (run<0>(blocks, X, W0, W1, W2, B0, B1, B2, ref, scale)) return 1;
     if (run<1>(blocks, X, W0, W1, W2, B0, B1, B2, ref, scale)) return 1;
     if (run<2>(blocks, X, W0, W1, W2, B0, B1, B2, ref, scale)) return 1;
+    if (run<3>(blocks, X, W0, W1, W2, B0, B1, B2, ref, scale)) return 1;
     return 0;
 }
