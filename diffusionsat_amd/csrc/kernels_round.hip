@@ -24,6 +24,9 @@
 #ifndef DSAT_SPLIT_PD1
 #define DSAT_SPLIT_PD1 3   // weight k-steps in flight per wave in the 16-row split chains
 #endif
+#ifndef DSAT_A1_ONE_RING
+#define DSAT_A1_ONE_RING 1   // role A's lit_mlp passes share one weight ring (split_vpass); 0: a ring per pass (round 2)
+#endif
 #ifndef DSAT_SPLIT_PD_A1
 #define DSAT_SPLIT_PD_A1 3   // ... in role A's 16-row lit_mlp
 #endif
@@ -656,30 +659,56 @@ __device__ __forceinline__ void role_a2(const RoundArgs& a, int tile, const Tile
     const unsigned short* h2in = r2 + row * LD2 + 8 * (lane >> 4);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 a0[2] = {z, z}, a0b[2] = {z, z}, a1[2] = {z, z}, a1b[2] = {z, z}, a2[2] = {z, z};
-    // L0, two passes; the first barrier also ends the reads of the fp32 rows h1 is about to overwrite
-    split_layer<2, PD>(voff, wb(0, wv, KS0), KS0, xin, BM * LDX, LDX, [] {}, a0);
     auto ep0a = [&]() {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) split_st4(h1, BM * LD1, (rb * 16 + row) * LD1 + wv * 16 + col4, leaky(a0[rb], b0a));
     };
-    split_layer<2, PD, false>(voff, wb(0, wv + 16, KS0), KS0, xin, BM * LDX, LDX, ep0a, a0b);
     auto ep0b = [&]() {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) split_st4(h1, BM * LD1, (rb * 16 + row) * LD1 + (wv + 16) * 16 + col4, leaky(a0b[rb], b0b));
     };
-    split_layer<2, PD>(voff, wb(1, wv, KS1), KS1, h1in, BM * LD1, LD1, ep0b, a1);            // L1 columns 0..255
     auto ep1a = [&]() {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) split_st4(r2, BM * LD2, (rb * 16 + row) * LD2 + wv * 16 + col4, leaky(a1[rb], b1a));
     };
-    split_layer<2, PD>(voff, wb(2, wv, KS2), KS2 / 2, h2in, BM * LD2, LD2, ep1a, a2);         // L2, k 0..255
-    split_layer<2, PD, false>(voff, wb(1, wv + 16, KS1), KS1, h1in, BM * LD1, LD1, [] {}, a1b);   // L1 columns 256..511
     auto ep1b = [&]() {
         lds_barrier();   // every wave is done with the first half of h2
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) split_st4(r2, BM * LD2, (rb * 16 + row) * LD2 + wv * 16 + col4, leaky(a1b[rb], b1b));
     };
+#if DSAT_A1_ONE_RING
+    // one ring across the six passes (split_vpass, as role_a1s): L0 twice, L1 columns 0..255, L2 k 0..255, L1 columns
+    // 256..511, L2 k 256..511; the first barrier also ends the reads of the fp32 rows h1 is about to overwrite
+    static_assert(KS0 >= PD && KS1 >= PD && KS2 / 2 >= PD, "a pass is at least one turn of the ring");
+    const float4* const pw[6] = {wb(0, wv, KS0), wb(0, wv + 16, KS0), wb(1, wv, KS1), wb(2, wv, KS2), wb(1, wv + 16, KS1),
+                                 wb(2, wv, KS2) + (size_t)(KS2 / 2) * 192};
+    constexpr int B1 = KS0, B2 = 2 * KS0, B3 = B2 + KS1, B4 = B3 + KS2 / 2, B5 = B4 + KS1;
+    SplitSlot ring[PD];
+    split_vprime<PD>(ring, voff, pw[0]);
+    lds_barrier();
+    split_vpass<2, PD>(ring, voff, pw[0], 0, KS0, pw[1], xin, BM * LDX, LDX, a0);
+    ep0a();
+    split_vpass<2, PD>(ring, voff, pw[1], B1, KS0, pw[2], xin, BM * LDX, LDX, a0b);
+    ep0b();
+    lds_barrier();
+    split_vpass<2, PD>(ring, voff, pw[2], B2, KS1, pw[3], h1in, BM * LD1, LD1, a1);
+    ep1a();
+    lds_barrier();
+    split_vpass<2, PD>(ring, voff, pw[3], B3, KS2 / 2, pw[4], h2in, BM * LD2, LD2, a2);
+    split_vpass<2, PD>(ring, voff, pw[4], B4, KS1, pw[5], h1in, BM * LD1, LD1, a1b);
+    ep1b();
+    lds_barrier();
+    split_vpass<2, PD>(ring, voff, pw[5], B5, KS2 / 2, pw[5] + (size_t)(KS2 / 2 - PD) * 192, h2in, BM * LD2, LD2, a2);
+    split_vdrain<PD>(ring);
+#else
+    // L0, two passes; the first barrier also ends the reads of the fp32 rows h1 is about to overwrite
+    split_layer<2, PD>(voff, wb(0, wv, KS0), KS0, xin, BM * LDX, LDX, [] {}, a0);
+    split_layer<2, PD, false>(voff, wb(0, wv + 16, KS0), KS0, xin, BM * LDX, LDX, ep0a, a0b);
+    split_layer<2, PD>(voff, wb(1, wv, KS1), KS1, h1in, BM * LD1, LD1, ep0b, a1);            // L1 columns 0..255
+    split_layer<2, PD>(voff, wb(2, wv, KS2), KS2 / 2, h2in, BM * LD2, LD2, ep1a, a2);         // L2, k 0..255
+    split_layer<2, PD, false>(voff, wb(1, wv + 16, KS1), KS1, h1in, BM * LD1, LD1, [] {}, a1b);   // L1 columns 256..511
     split_layer<2, PD>(voff, wb(2, wv, KS2) + (size_t)(KS2 / 2) * 192, KS2 / 2, h2in, BM * LD2, LD2, ep1b, a2);   // L2, k 256..511
+#endif
     // R6: literals = [lit_mlp(v1)[:, :128] ; [:, 128:]]
     float* lits = a.lits;
     const int col = wv * 16 + col4;
@@ -701,9 +730,6 @@ __device__ __forceinline__ void role_a2(const RoundArgs& a, int tile, const Tile
 // kernel).  Used when role B covers every row of the batch (the tile then is PairNorm + lit_mlp only) and
 // role A is not on 32-row tiles.  LDS: h1 [3][16][528] (first the fp32 PairNorm rows) | h2 [3][16][528] | v1 planes
 // [3][16][176] | mean: 116 KB.
-#ifndef DSAT_A1_ONE_RING
-#define DSAT_A1_ONE_RING 1
-#endif
 __device__ __forceinline__ void role_a1s(const RoundArgs& a, int tile, const TileMetaDev& tm, float* smem, int tid) {
     constexpr int BM = 16, PD = DSAT_SPLIT_PD_A1;
     constexpr int KS0 = (F + AUX_W + 31) / 32, LDX = KS0 * 32 + 16, HID = 512, LD1 = HID + 16;
