@@ -28,7 +28,7 @@
 #define DSAT_A1_ONE_RING 1   // role A's lit_mlp passes share one weight ring (split_vpass); 0: a ring per pass (round 2)
 #endif
 #ifndef DSAT_SPLIT_PD_A1
-#define DSAT_SPLIT_PD_A1 3   // ... in role A's 16-row lit_mlp
+#define DSAT_SPLIT_PD_A1 2   // ... in role A's 16-row lit_mlp (one ring across the passes: 2 / 3 / 4 -> 376.5 / 375.1 / 375.0 steps/s)
 #endif
 #include "philox.h"
 
