@@ -241,7 +241,9 @@ __device__ __forceinline__ void vpass(SplitSlot (&ring)[PD], unsigned voff, cons
             if (V >= B && V < E) {
                 const int k = V - B;
                 const unsigned short* q = px + k * 32;
+#ifndef X_NO_ROT
                 split_rotate_prio(k);
+#endif
 #ifdef X_NO_LDS
                 bf16x8 xh = __builtin_bit_cast(bf16x8, ring[(p + 1) % PD].h), xm = xh, xl = xh; (void)q;
                 asm volatile("" : "+v"(xh));
@@ -251,7 +253,11 @@ __device__ __forceinline__ void vpass(SplitSlot (&ring)[PD], unsigned voff, cons
 #endif
                 asm volatile("s_waitcnt vmcnt(%3)" : "+v"(ring[p].h), "+v"(ring[p].m), "+v"(ring[p].l) : "n"(3 * (PD - 1)) : "memory");
 #ifdef X_NO_MFMA
-                acc[0][0] += ring[p].h[0] + ring[p].m[1] + ring[p].l[2] + __builtin_bit_cast(sf32x4, xh)[0] + __builtin_bit_cast(sf32x4, xm)[1] + __builtin_bit_cast(sf32x4, xl)[2];
+                asm volatile("" :: "v"(xh), "v"(xm), "v"(xl));   // the LDS reads stay, nothing consumes the weights
+#elif defined(X_TWO_MFMA)
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[p].h), xh, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[p].m), xm, acc[0], 0, 0, 0);
+                asm volatile("" :: "v"(xl), "v"(ring[p].l));
 #else
                 split_step<1>(ring[p], xh, xm, xl, q, plane, ld, acc);
 #endif
@@ -325,12 +331,16 @@ __global__ __launch_bounds__(NTH) void kern(Args a) {
         vpass<PDV>(ring, voff, base[1], KS0, KS0, base[2], xin, ROWS * LDX, LDX, t0b);
         split_st4(h1, ROWS * LD1, row * LD1 + wv * 16 + col4, leaky(t0a[0], b0a));
         split_st4(h1, ROWS * LD1, row * LD1 + (wv + 16) * 16 + col4, leaky(t0b[0], b0b));
+#ifndef X_NO_BARRIER
         lds_barrier();
+#endif
         vpass<PDV>(ring, voff, base[2], 2 * KS0, KS1, base[3], h1in, ROWS * LD1, LD1, t1a);
         vpass<PDV>(ring, voff, base[3], 2 * KS0 + KS1, KS1, base[4], h1in, ROWS * LD1, LD1, t1b);
         split_st4(h2, ROWS * LD1, row * LD1 + wv * 16 + col4, leaky(t1a[0], b1a));
         split_st4(h2, ROWS * LD1, row * LD1 + (wv + 16) * 16 + col4, leaky(t1b[0], b1b));
+#ifndef X_NO_BARRIER
         lds_barrier();
+#endif
         vpass<PDV>(ring, voff, base[4], 2 * KS0 + 2 * KS1, KS2, base[4] + (size_t)(KS2 - PDV) * 192, h2in, ROWS * LD1, LD1, a2);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0].h), "+v"(ring[0].m), "+v"(ring[0].l) :: "memory");
 #pragma unroll
@@ -467,9 +477,11 @@ int main(int argc, char** argv) {
         for (int n = 0; n < N1; ++n) { double t = B1[n]; for (int k = 0; k < N0; ++k) t += h1[k] * W1[(size_t)k * N1 + n]; h2[n] = std::max(t, 0.2 * t); }
         for (int n = 0; n < N2; ++n) { double t = B2[n]; for (int k = 0; k < N1; ++k) t += h2[k] * W2[(size_t)k * N2 + n]; ref[(size_t)r * N2 + n] = t; scale = std::max(scale, std::fabs(t)); }
     }
+#ifndef ONLY_MODE3
     if (run<0>(blocks, X, W0, W1, W2, B0, B1, B2, ref, scale)) return 1;
     if (run<1>(blocks, X, W0, W1, W2, B0, B1, B2, ref, scale)) return 1;
     if (run<2>(blocks, X, W0, W1, W2, B0, B1, B2, ref, scale)) return 1;
+#endif
     if (run<3>(blocks, X, W0, W1, W2, B0, B1, B2, ref, scale)) return 1;
     return 0;
 }
