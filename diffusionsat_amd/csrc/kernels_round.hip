@@ -27,6 +27,9 @@
 #ifndef DSAT_A1_ONE_RING
 #define DSAT_A1_ONE_RING 1   // role A's lit_mlp passes share one weight ring (split_vpass); 0: a ring per pass (round 2)
 #endif
+#ifndef DSAT_A1_EARLY
+#define DSAT_A1_EARLY 1      // role_a1s asks for its biases before the PairNorm and primes the ring before v1 is sliced
+#endif
 #ifndef DSAT_SPLIT_PD_A1
 #define DSAT_SPLIT_PD_A1 2   // ... in role A's 16-row lit_mlp (one ring across the passes: 2 / 3 / 4 -> 376.5 / 375.1 / 375.0 steps/s)
 #endif
@@ -745,6 +748,19 @@ __device__ __forceinline__ void role_a1s(const RoundArgs& a, int tile, const Til
     constexpr int ldS = F + AUX_W + 8;
     float* sPart = sState + BM * ldS;                                       // NT / F rows of F floats
     static_assert((BM * ldS + (NT / F) * F) * 4 <= 3 * BM * LD1 * 2, "PairNorm scratch fits h1");
+#if DSAT_A1_EARLY
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff = (unsigned)lane * 16u;
+    const int col4 = 4 * (lane >> 4), row = lane & 15;
+    auto wb = [&](int l, int t, int ks) { return reinterpret_cast<const float4*>(a.a2_ws[l]) + ((size_t)t * ks * 3) * 64; };
+    // (the biases: requested before the PairNorm, whose latency hides theirs; pinned -- completed -- behind it)
+    auto leaky = [](f32x4 acc, float4 b) { return bias_act(acc, b, 1); };
+    float4 b0a = *reinterpret_cast<const float4*>(a.mlit.L[0].bias + wv * 16 + col4);
+    float4 b0b = *reinterpret_cast<const float4*>(a.mlit.L[0].bias + (wv + 16) * 16 + col4);
+    float4 b1a = *reinterpret_cast<const float4*>(a.mlit.L[1].bias + wv * 16 + col4);
+    float4 b1b = *reinterpret_cast<const float4*>(a.mlit.L[1].bias + (wv + 16) * 16 + col4);
+    float4 b2 = *reinterpret_cast<const float4*>(a.mlit.L[2].bias + wv * 16 + col4);
+#endif
     DSAT_STAMP_RT_BEGIN(a);
     DSAT_STAMP(a, 0);
     if (tid < BM) {   // aux columns of v1 for this round
@@ -756,12 +772,24 @@ __device__ __forceinline__ void role_a1s(const RoundArgs& a, int tile, const Til
     DSAT_STAMP(a, 1);
     DSAT_STAMP(a, 2);
     DSAT_STAMP(a, 3);
+#if DSAT_A1_EARLY
+    asm volatile("" : "+v"(b0a.x), "+v"(b0a.y), "+v"(b0a.z), "+v"(b0a.w), "+v"(b0b.x), "+v"(b0b.y), "+v"(b0b.z), "+v"(b0b.w));
+    asm volatile("" : "+v"(b1a.x), "+v"(b1a.y), "+v"(b1a.z), "+v"(b1a.w), "+v"(b1b.x), "+v"(b1b.y), "+v"(b1b.z), "+v"(b1b.w));
+    asm volatile("" : "+v"(b2.x), "+v"(b2.y), "+v"(b2.z), "+v"(b2.w));
+#if DSAT_A1_ONE_RING
+    // the ring's first fragments travel while v1 is sliced (LDS work only: nothing else enters the vmcnt queue)
+    const float4* const pw[5] = {wb(0, wv, KS0), wb(0, wv + 16, KS0), wb(1, wv, KS1), wb(1, wv + 16, KS1), wb(2, wv, KS2)};
+    SplitSlot ring[PD];
+    split_vprime<PD>(ring, voff, pw[0]);
+#endif
+#endif
     // v1 = [state | aux | zeros up to the last k-step] as slices
     for (int i = tid; i < BM * (KS0 * 8); i += NT) {
         const int r = i / (KS0 * 8), c = 4 * (i % (KS0 * 8));
         const float4 v = c < F + AUX_W ? ld4(sState + r * ldS + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         split_st4(xs, BM * LDX, r * LDX + c, v);
     }
+#if !DSAT_A1_EARLY
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const unsigned voff = (unsigned)lane * 16u;
     const int col4 = 4 * (lane >> 4), row = lane & 15;
@@ -775,6 +803,7 @@ __device__ __forceinline__ void role_a1s(const RoundArgs& a, int tile, const Til
     asm volatile("" : "+v"(b0a.x), "+v"(b0a.y), "+v"(b0a.z), "+v"(b0a.w), "+v"(b0b.x), "+v"(b0b.y), "+v"(b0b.z), "+v"(b0b.w));
     asm volatile("" : "+v"(b1a.x), "+v"(b1a.y), "+v"(b1a.z), "+v"(b1a.w), "+v"(b1b.x), "+v"(b1b.y), "+v"(b1b.z), "+v"(b1b.w));
     asm volatile("" : "+v"(b2.x), "+v"(b2.y), "+v"(b2.z), "+v"(b2.w));
+#endif
     const unsigned short* xin = xs + row * LDX + 8 * (lane >> 4);
     const unsigned short* h1in = h1 + row * LD1 + 8 * (lane >> 4);
     const unsigned short* h2in = h2 + row * LD1 + 8 * (lane >> 4);
@@ -785,9 +814,11 @@ __device__ __forceinline__ void role_a1s(const RoundArgs& a, int tile, const Til
 #if DSAT_A1_ONE_RING
     // one ring across the five passes (split_vpass): the next pass's first fragments travel during this one's last steps
     static_assert(KS0 >= PD && KS1 >= PD && KS2 >= PD, "a pass is at least one turn of the ring");
+#if !DSAT_A1_EARLY
     const float4* const pw[5] = {wb(0, wv, KS0), wb(0, wv + 16, KS0), wb(1, wv, KS1), wb(1, wv + 16, KS1), wb(2, wv, KS2)};
     SplitSlot ring[PD];
     split_vprime<PD>(ring, voff, pw[0]);
+#endif
     lds_barrier();   // v1's planes are published; also ends the reads of the fp32 rows h1 is about to overwrite
     split_vpass<1, PD>(ring, voff, pw[0], 0, KS0, pw[1], xin, BM * LDX, LDX, a0a);
     split_vpass<1, PD>(ring, voff, pw[1], KS0, KS0, pw[2], xin, BM * LDX, LDX, a0b);
