@@ -33,8 +33,9 @@ def test_round_kernels_spill_nothing_and_pad_their_asm_stores(tmp_path):
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not on PATH")
     out = tmp_path / "kr.s"
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-                           "-S", "--cuda-device-only", "-o", str(out),
+    sys.path.insert(0, ROOT)
+    from diffusionsat_amd.build import FLAGS      # the shipped library's flags
+    subprocess.check_call(["hipcc"] + [f for f in FLAGS if f != "-fPIC"] + ["-S", "--cuda-device-only", "-o", str(out),
                            os.path.join(ROOT, "diffusionsat_amd", "csrc", "kernels_round.hip")], stderr=subprocess.DEVNULL)
     text = out.read_text()
     import re

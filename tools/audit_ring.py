@@ -19,8 +19,10 @@ import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "diffusionsat_amd", "csrc", sys.argv[1] if len(sys.argv) > 1 else "kernels_round.hip")
 out = "/tmp/kr_audit_%s_%d.s" % (os.path.basename(src), os.getpid())
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-                       "-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
+sys.path.insert(0, root)
+from diffusionsat_amd.build import FLAGS   # the flags the shipped library is built with: the audited ISA is the shipped ISA
+subprocess.check_call(["hipcc"] + [f for f in FLAGS if f != "-fPIC"] + ["-S", "--cuda-device-only", "-o", out, src],
+                      stderr=subprocess.DEVNULL)
 text = open(out).read()
 
 
