@@ -27,9 +27,6 @@
 #ifndef DSAT_A1_ONE_RING
 #define DSAT_A1_ONE_RING 1   // role A's lit_mlp passes share one weight ring (split_vpass); 0: a ring per pass (round 2)
 #endif
-#ifndef DSAT_SPLIT_PD_A2
-#define DSAT_SPLIT_PD_A2 DSAT_SPLIT_PD4   // ... in role A's 32-row lit_mlp (and the pair's chains when that tile runs them)
-#endif
 #ifndef DSAT_A1_EARLY
 #define DSAT_A1_EARLY 1      // role_a1s asks for its biases before the PairNorm and primes the ring before v1 is sliced
 #endif
@@ -566,7 +563,7 @@ __device__ __forceinline__ void clause_norm_block(const RoundArgs& a, int b, int
 // which lit_mlp's first layer only overwrites afterwards; the query chain reads the v1 planes lit_mlp reads too.
 __device__ __forceinline__ void role_a2(const RoundArgs& a, int tile, const TileMetaDev& tm, float* smem, int tid,
                                         bool pair_here) {
-    constexpr int BM = 32, PD = DSAT_SPLIT_PD_A2;
+    constexpr int BM = 32, PD = DSAT_SPLIT_PD4;
     constexpr int KS0 = (F + AUX_W + 31) / 32, LDX = KS0 * 32 + 16, HID = 512, LD1 = HID + 16, LD2 = HID / 2 + 16;
     constexpr int KS1 = HID / 32, KS2 = HID / 32;
     const int wave = tid >> 6, lane = tid & 63;
